@@ -1,0 +1,28 @@
+# Builds the product libraries in-tree and the CPU oracle used by the tests.
+#   raytracer_amd/librt_gpu.so   HIP rendering core (gfx950), C ABI include/gpu_render.h
+#   raytracer_amd/librt_host.so  host library: scene ingest, BVH build, tone map, image files
+#   raytracer                    command-line front end (same argv contract as the reference)
+#   oracle/liboracle.so          CPU checker (tests only); oracle/_ref/* when the reference is present
+HIPCC ?= hipcc
+CXX ?= g++
+HOST_SRCS = $(addprefix raytracer_amd/csrc/host/,ingest.cpp ply.cpp bvh_build.cpp image_io.cpp jpeg.cpp tonemap.cpp host_api.cpp)
+HOST_HDRS = $(wildcard raytracer_amd/csrc/host/*.h) include/gpu_render.h include/rt_host.h
+HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -std=c++17 -Iinclude -Iraytracer_amd/csrc/gpu
+
+all: raytracer_amd/librt_gpu.so raytracer_amd/librt_host.so raytracer oracle
+
+raytracer_amd/librt_gpu.so: raytracer_amd/csrc/gpu/render.hip raytracer_amd/csrc/gpu/rt_math.h include/gpu_render.h
+	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+
+raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
+	$(CXX) -std=c++17 -O2 -fPIC -shared -Wall -Iinclude -Iraytracer_amd/csrc/host $(HOST_SRCS) -lz -o $@
+
+raytracer: raytracer_amd/csrc/host/main.cpp raytracer_amd/librt_host.so raytracer_amd/librt_gpu.so
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Iraytracer_amd/csrc/host $< -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f raytracer_amd/*.so raytracer oracle/liboracle.so
+.PHONY: all oracle clean

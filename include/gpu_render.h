@@ -1,0 +1,274 @@
+/*
+ * gpu_render.h — C ABI of the MI355X rendering core.
+ *
+ * The reference renderer has no plugin/FFI layer; the seam this header defines is the body of the
+ * per-camera loop of process_file() (reference src/main.cpp:428-559): everything between
+ * "hdr_output allocated" (:435) and "rendering done" (:557-559).  The host program ingests the
+ * JSON/PLY scene, builds the SAH BVH, flattens everything into the plain arrays below and calls:
+ *
+ *     rt_scene_create   replaces  `new ray_tracer(...)`          (src/main.cpp:421, src/ray_trace.h:53-65)
+ *     rt_render         replaces  the std::thread scheduler block (src/main.cpp:437-555) and all it calls
+ *     rt_scene_destroy  replaces  `delete rt`                     (src/main.cpp:625)
+ *
+ * All structs are plain C, pointers + counts, 4-byte scalars only.  Matrices are the first three
+ * rows of a row-major 4x4 (12 floats); the 4th row of an affine matrix is never read on the path.
+ */
+#ifndef GPU_RENDER_H
+#define GPU_RENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ---- enums (values follow the reference's enum order) ---------------------------------------- */
+enum { RT_MAT_REGULAR = 0, RT_MAT_MIRROR = 1, RT_MAT_CONDUCTOR = 2, RT_MAT_DIELECTRIC = 3 }; /* src/shapes.h:20-26 */
+enum { RT_BRDF_ORIGINAL_BLINN_PHONG = 0, RT_BRDF_ORIGINAL_PHONG = 1, RT_BRDF_MODIFIED_BLINN_PHONG = 2,
+       RT_BRDF_MODIFIED_PHONG = 3, RT_BRDF_TORRANCE_SPARROW = 4 };                           /* src/shapes.h:37-44 */
+enum { RT_DECAL_REPLACE_KD = 0, RT_DECAL_BLEND_KD = 1, RT_DECAL_REPLACE_KS = 2, RT_DECAL_REPLACE_BACKGROUND = 3,
+       RT_DECAL_REPLACE_NORMAL = 4, RT_DECAL_BUMP_NORMAL = 5, RT_DECAL_REPLACE_ALL = 6 };    /* src/texture.h:19-28 */
+enum { RT_INTERP_NEAREST = 0, RT_INTERP_BILINEAR = 1 };                                      /* src/texture.h:30-34 */
+enum { RT_NOISE_ABSVAL = 0, RT_NOISE_LINEAR = 1 };                                           /* src/texture.h:36-40 */
+enum { RT_TEX_IMAGE = 0, RT_TEX_CHECKER = 1, RT_TEX_PERLIN = 2 };
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1, RT_LIGHT_DIRECTIONAL = 2, RT_LIGHT_SPOT = 3,
+       RT_LIGHT_ENV = 4, RT_LIGHT_TRIANGLE = 5, RT_LIGHT_SPHERE = 6 };                       /* src/lights.h */
+enum { RT_TMO_PHOTOGRAPHIC = 0, RT_TMO_FILMIC = 1, RT_TMO_ACES = 2 };                        /* src/camera.h:6-11 */
+
+/* ---- scene records ---------------------------------------------------------------------------- */
+
+/* material (src/shapes.h:46-61) */
+typedef struct rt_material {
+    int32_t type;        /* RT_MAT_* */
+    int32_t brdf;        /* RT_BRDF_* */
+    int32_t normalized;
+    int32_t kdfresnel;
+    float ambient[3];
+    float diffuse[3];
+    float specular[3];
+    float phong_exponent;
+    float mirror[3];
+    float absorption_coefficient[3];
+    float refraction_index;
+    float absorption_index;
+    float roughness;
+} rt_material;
+
+/* one mesh placement = one entry of all_mesh_infos::mesh_infos (src/shapes.h:70-84) */
+typedef struct rt_instance {
+    float model[12];
+    float inv_model[12];
+    float normal[12];      /* transpose(inverse(model)), rows 0..2 */
+    float motionblur[3];
+    float emission[3];
+    int32_t material;      /* index into materials */
+    int32_t tex_offset;    /* range in texture_refs */
+    int32_t tex_count;
+    int32_t ref_id;        /* the reference's instance id: mesh _id, MeshInstance _id, or 123456 */
+    int32_t identity;      /* 1 when model is exactly the identity (inverse transform is a no-op) */
+} rt_instance;
+
+/* triangle in OBJECT space (src/shapes.h:110-149).  The reference intersects in object space with
+ * vertices scaled by 1000 (src/shapes.cpp:212-279); the scaled values are derived by the core. */
+typedef struct rt_triangle {
+    float c1[3], c2[3], c3[3];
+    float n1[3], n2[3], n3[3];   /* per-vertex normals when smooth */
+    float tex_u[3], tex_v[3];    /* per-vertex texture coordinates */
+    int32_t smooth;
+} rt_triangle;
+
+/* sphere (src/shapes.h:151-184) */
+typedef struct rt_sphere {
+    float center[3];
+    float radius;
+    float model[12];
+    float inv_model[12];
+    float normal[12];
+    float emission[3];
+    int32_t material;
+    int32_t tex_offset;
+    int32_t tex_count;
+} rt_sphere;
+
+/* unbounded plane, already in world space (src/shapes.h:186-204, src/parser.cpp:1020-1067) */
+typedef struct rt_plane {
+    float point[3];
+    float normal[3];
+    int32_t material;
+    int32_t tex_offset;
+    int32_t tex_count;
+} rt_plane;
+
+/* decoded image (src/texture.h:4-17): 8-bit RGB (3 bytes/texel) or float RGBA (4 floats/texel) */
+typedef struct rt_image {
+    int32_t width, height;
+    int32_t is_hdr;
+    int32_t offset;        /* texel offset: bytes into texels_u8 or floats into texels_f32 */
+} rt_image;
+
+/* texture map (src/texture.h:42-62) */
+typedef struct rt_texture {
+    int32_t kind;          /* RT_TEX_* */
+    int32_t image;         /* index into images or -1 */
+    int32_t decal_mode;    /* RT_DECAL_* */
+    int32_t interp;        /* RT_INTERP_* */
+    float bump_factor;
+    float noise_scale;
+    int32_t noise_conversion;
+    float num_octaves;
+    float black[3];
+    float white[3];
+    float scale;
+    float offset;
+} rt_texture;
+
+/* light (src/lights.h).  Field use by type:
+ *   POINT       position, color=intensity
+ *   AREA        position, normal (as parsed, not normalised), u, v (basis), size, color=radiance, samples
+ *   DIRECTIONAL direction (normalised), color=radiance
+ *   SPOT        position, direction (normalised), color=intensity, cos_coverage, cos_falloff
+ *   ENV         image, cosine_sampling, is_probe
+ *   TRIANGLE    v0,v1,v2 = world vertices, normal, area, color=radiance            (samples 16)
+ *   SPHERE      position=centre (object space), size=radius, sphere = index of the rt_sphere,
+ *               area = 4*pi*|model*(r,0,0)|^2, color=radiance                       (samples 16)
+ */
+typedef struct rt_light {
+    int32_t type;
+    int32_t samples;
+    float position[3];
+    float direction[3];
+    float normal[3];
+    float u[3], v[3];
+    float v0[3], v1[3], v2[3];
+    float color[3];
+    float size;
+    float area;
+    float cos_coverage, cos_falloff;
+    int32_t image;
+    int32_t cosine_sampling;
+    int32_t is_probe;
+    int32_t sphere;
+} rt_light;
+
+/* flattened BVH in the reference's depth-first layout (src/bvh.h:12-28, src/bvh.cpp:316-343):
+ * the left child of interior node i is i+1, the right child is `offset`. */
+typedef struct rt_bvh_node {
+    float bmin[3];
+    float bmax[3];
+    int32_t offset;        /* leaf: first entry in prims; interior: index of the second child */
+    int32_t n_prims;       /* 0 for interior nodes */
+    int32_t axis;          /* split axis of interior nodes */
+} rt_bvh_node;
+
+/* leaf entry = (shape, placement) pair (src/bvh.h:24-28).  Shapes are numbered in the order of
+ * parser::get_shapes(): all triangles, then spheres, then planes. */
+typedef struct rt_bvh_prim {
+    int32_t shape;         /* < n_triangles: triangle; else sphere (shape - n_triangles) */
+    int32_t instance;      /* index into instances for triangles, -1 for spheres */
+} rt_bvh_prim;
+
+typedef struct rt_scene_desc {
+    int32_t abi_version;
+
+    int32_t n_triangles;   const rt_triangle *triangles;
+    int32_t n_instances;   const rt_instance *instances;
+    int32_t n_spheres;     const rt_sphere *spheres;
+    int32_t n_planes;      const rt_plane *planes;
+    int32_t n_materials;   const rt_material *materials;
+    int32_t n_textures;    const rt_texture *textures;
+    int32_t n_texture_refs; const int32_t *texture_refs;   /* per-object texture index lists */
+    int32_t n_images;      const rt_image *images;
+    int64_t n_texels_u8;   const uint8_t *texels_u8;
+    int64_t n_texels_f32;  const float *texels_f32;
+    int32_t n_lights;      const rt_light *lights;
+
+    int32_t n_bvh_nodes;   const rt_bvh_node *bvh_nodes;
+    int32_t n_bvh_prims;   const rt_bvh_prim *bvh_prims;
+
+    float intersection_epsilon;   /* src/parser.cpp:1239-1244 */
+    float shadow_ray_epsilon;     /* src/parser.cpp:1246-1251 */
+    float max_depth;              /* src/parser.cpp:1253-1258 (kept as float, compared with int depth) */
+    float ambient_light[3];
+    float background_color[3];
+    int32_t background_texture;   /* index into textures, or -1 (src/main.cpp:380-417) */
+    int32_t is_probe;
+} rt_scene_desc;
+
+/* post-constructor camera state (src/camera.h:35-56) + RenderSettings (src/camera.h:23-33) */
+typedef struct rt_camera_desc {
+    float position[3];
+    float u[3], v[3], w[3];
+    float center[3];
+    float near_left, near_right, near_bottom, near_top;
+    int32_t resx, resy;
+    int32_t num_samples;
+    float focus_distance;
+    float aperture_size;
+    int32_t is_hdr;
+    int32_t path_tracing;
+    int32_t importance_sampling;
+    int32_t next_event_estimation;
+    int32_t russian_roulette;
+    int32_t splitting_factor;
+    float sample_max_val;
+    int32_t min_recursion_depth;
+    uint32_t seed;           /* the reference's RNG is unseedable; the core's is counter based */
+} rt_camera_desc;
+
+typedef struct rt_stats {
+    uint64_t primary_rays;
+    uint64_t shadow_rays;
+    uint64_t secondary_rays;
+    uint64_t nodes_visited;      /* BVH nodes whose box was tested */
+    uint64_t triangle_tests;
+    uint64_t sphere_tests;
+    uint64_t plane_tests;
+    uint64_t shaded_hits;
+    uint64_t texel_fetches;
+    float kernel_ms;             /* device time of the render kernels of the last call */
+    float total_ms;              /* wall time of the call including copies */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+/* Copies every array of `desc` to the current HIP device; the caller may free them on return.
+ * Returns 0 on success. */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+
+/* Renders one camera synchronously.  hdr_out: caller-owned host or device memory, resx*resy*3
+ * floats, interleaved RGB, row 0 = bottom image row (index = j*resx + i, src/main.cpp:453).
+ * stats may be NULL.  Returns 0 on success. */
+int rt_render(rt_scene *scene, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats);
+
+/* Image-space shard of one frame (32x32 tiles, the reference's square_dynamic tile size,
+ * src/main.cpp:441): renders only the tiles owned by `rank` of `world` into hdr_out at their
+ * full-frame positions; other pixels are left untouched. */
+int rt_render_shard(rt_scene *scene, const rt_camera_desc *cam, int32_t rank, int32_t world, float *hdr_out,
+                    rt_stats *stats);
+
+/* Primary visibility only (bvh::intersect for each pixel's first sample, src/bvh.cpp:383-480):
+ * shape index, reference instance id (-1/-1 on a miss) and hit distance (1e30 on a miss). */
+int rt_trace_primary(rt_scene *scene, const rt_camera_desc *cam, int32_t *shape_out, int32_t *id_out, float *t_out,
+                     rt_stats *stats);
+
+/* Enables per-ray traversal counters (nodes visited, primitive tests) in subsequent renders. */
+int rt_set_counters(rt_scene *scene, int32_t enabled);
+
+void rt_scene_destroy(rt_scene *scene);
+
+/* Self-test hook: evaluates arithmetic definition `fn` of the core on the device for n element
+ * pairs (0 sin, 1 cos, 2 asin, 3 acos, 4 atan2, 5 exp, 6 log, 7 pow, 8 divide, 9 sqrt, 10 random
+ * number from (key, dimension) bit patterns, 11 x*y+x unfused).  Used to check that device
+ * arithmetic is bit-identical to a strict IEEE-754 evaluation on the host. */
+int rt_selftest_math(int32_t fn, int32_t n, const float *a, const float *b, float *out);
+
+/* Message of the last failing call on this thread ("" if none).  The reference's convention is
+ * print + exit(code) (src/main.cpp:544,654; src/parser.cpp:855); the ABI returns nonzero instead. */
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+// SAH BVH construction on the host (reference src/bvh.cpp:41-344).
+//
+// 12-bucket surface-area heuristic on the axis of largest centroid extent, traversal cost 0.125,
+// a leaf when n <= 4 and no split is cheaper than n, an equal-count split when the SAH partition
+// degenerates.  Nodes are emitted directly in depth-first pre-order, which is the layout the
+// reference produces with its separate flatten pass (left child = i+1, right child = offset).
+// std::partition / std::nth_element are used exactly where the reference uses them so that the
+// primitive order inside every subtree — and with it the order in which equal-distance hits are
+// found — is the same.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "scene.h"
+
+namespace rth {
+
+namespace {
+
+struct BuildItem {
+    int prim;
+    float bmin[3], bmax[3], c[3];
+};
+
+struct Builder {
+    std::vector<BuildItem> items;
+    std::vector<rt_bvh_node> nodes;
+    std::vector<int> order;   // prim numbers in leaf order
+
+    static float surface_area(const float *mn, const float *mx) {
+        float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        if (x < 0 || y < 0 || z < 0) return 0.0f;
+        return 2.f * (x * y + x * z + y * z);
+    }
+
+    void make_leaf(int node, int start, int end) {
+        nodes[node].offset = (int)order.size();
+        nodes[node].n_prims = end - start;
+        nodes[node].axis = 0;
+        for (int i = start; i < end; ++i) order.push_back(items[i].prim);
+    }
+
+    int build(int start, int end) {
+        const int node = (int)nodes.size();
+        nodes.emplace_back();
+        float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = start; i < end; ++i)
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], items[i].bmin[a]);
+                mx[a] = std::max(mx[a], items[i].bmax[a]);
+            }
+        memcpy(nodes[node].bmin, mn, sizeof mn);
+        memcpy(nodes[node].bmax, mx, sizeof mx);
+
+        const int n = end - start;
+        if (n == 1) {
+            make_leaf(node, start, end);
+            return node;
+        }
+        float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = start; i < end; ++i)
+            for (int a = 0; a < 3; ++a) {
+                cmn[a] = std::min(cmn[a], items[i].c[a]);
+                cmx[a] = std::max(cmx[a], items[i].c[a]);
+            }
+        int dim = 0;
+        float extent = cmx[0] - cmn[0];
+        if ((cmx[1] - cmn[1]) > extent) {
+            dim = 1;
+            extent = cmx[1] - cmn[1];
+        }
+        if ((cmx[2] - cmn[2]) > extent) dim = 2;   // the reference leaves `extent` at the x/y value here
+        if (extent < 1e-5f) {
+            make_leaf(node, start, end);
+            return node;
+        }
+
+        constexpr int NB = 12;
+        struct Bucket {
+            int count = 0;
+            float mn[3], mx[3];
+        } buckets[NB];
+        const float k1 = NB * (1.0f - 1e-4f) / extent;
+        const float cmin = cmn[dim];
+        auto bucket_of = [=](const BuildItem &it) {
+            int b = (int)((it.c[dim] - cmin) * k1);
+            if (b < 0) b = 0;
+            if (b >= NB) b = NB - 1;
+            return b;
+        };
+        for (int i = start; i < end; ++i) {
+            Bucket &b = buckets[bucket_of(items[i])];
+            if (b.count++ == 0) {
+                memcpy(b.mn, items[i].bmin, sizeof b.mn);
+                memcpy(b.mx, items[i].bmax, sizeof b.mx);
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    b.mn[a] = std::min(b.mn[a], items[i].bmin[a]);
+                    b.mx[a] = std::max(b.mx[a], items[i].bmax[a]);
+                }
+            }
+        }
+        float cost[NB - 1];
+        const float parent_sa = surface_area(mn, mx);
+        for (int i = 0; i < NB - 1; ++i) {
+            float mn0[3] = {0, 0, 0}, mx0[3] = {0, 0, 0}, mn1[3] = {0, 0, 0}, mx1[3] = {0, 0, 0};
+            int c0 = 0, c1 = 0;
+            bool init0 = false, init1 = false;
+            auto grow = [](float *dmn, float *dmx, bool &init, const Bucket &b) {
+                if (!init) {
+                    memcpy(dmn, b.mn, 12);
+                    memcpy(dmx, b.mx, 12);
+                    init = true;
+                } else {
+                    for (int a = 0; a < 3; ++a) {
+                        dmn[a] = std::min(dmn[a], b.mn[a]);
+                        dmx[a] = std::max(dmx[a], b.mx[a]);
+                    }
+                }
+            };
+            for (int j = 0; j <= i; ++j)
+                if (buckets[j].count) {
+                    c0 += buckets[j].count;
+                    grow(mn0, mx0, init0, buckets[j]);
+                }
+            for (int j = i + 1; j < NB; ++j)
+                if (buckets[j].count) {
+                    c1 += buckets[j].count;
+                    grow(mn1, mx1, init1, buckets[j]);
+                }
+            cost[i] = 0.125f + (c0 * surface_area(mn0, mx0) + c1 * surface_area(mn1, mx1)) / parent_sa;
+        }
+        float min_cost = cost[0];
+        int split_bucket = 0;
+        for (int i = 1; i < NB - 1; ++i)
+            if (cost[i] < min_cost) {
+                min_cost = cost[i];
+                split_bucket = i;
+            }
+        if (n > 4 || min_cost < (float)n) {
+            auto pmid = std::partition(items.begin() + start, items.begin() + end,
+                                       [=](const BuildItem &it) { return bucket_of(it) <= split_bucket; });
+            int mid = (int)(pmid - items.begin());
+            if (mid == start || mid == end) {
+                mid = start + (end - start) / 2;
+                std::nth_element(items.begin() + start, items.begin() + mid, items.begin() + end,
+                                 [dim](const BuildItem &a, const BuildItem &b) { return a.c[dim] < b.c[dim]; });
+            }
+            nodes[node].axis = dim;
+            nodes[node].n_prims = 0;
+            build(start, mid);
+            int second = build(mid, end);
+            nodes[node].offset = second;
+        } else {
+            make_leaf(node, start, end);
+        }
+        return node;
+    }
+};
+
+}  // namespace
+
+void build_bvh(HostScene &scene) {
+    scene.bvh_nodes.clear();
+    scene.bvh_prims.clear();
+    const size_t n = scene.build_prims.size();
+    if (n == 0) return;
+    Builder b;
+    b.items.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        BuildItem &it = b.items[i];
+        it.prim = (int)i;
+        memcpy(it.bmin, scene.build_bounds[i].bmin, 12);
+        memcpy(it.bmax, scene.build_bounds[i].bmax, 12);
+        for (int a = 0; a < 3; ++a) it.c[a] = (it.bmin[a] + it.bmax[a]) * 0.5f;
+    }
+    b.nodes.reserve(2 * n);
+    b.order.reserve(n);
+    b.build(0, (int)n);
+    scene.bvh_nodes = std::move(b.nodes);
+    scene.bvh_prims.resize(n);
+    for (size_t i = 0; i < n; ++i) scene.bvh_prims[i] = scene.build_prims[b.order[i]];
+}
+
+}  // namespace rth
