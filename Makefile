@@ -18,7 +18,7 @@ raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) -std=c++17 -O2 -fPIC -shared -Wall -Iinclude -Iraytracer_amd/csrc/host $(HOST_SRCS) -lz -o $@
 
 raytracer: raytracer_amd/csrc/host/main.cpp raytracer_amd/librt_host.so raytracer_amd/librt_gpu.so
-	$(CXX) -std=c++17 -O2 -Wall -Iinclude -Iraytracer_amd/csrc/host $< -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@
+	$(CXX) -std=c++17 -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Iraytracer_amd/csrc/host $< -L/opt/rocm/lib -lamdhip64 -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@
 
 oracle:
 	$(MAKE) -C oracle all

@@ -95,7 +95,11 @@ typedef struct rt_sphere {
 /* unbounded plane, already in world space (src/shapes.h:186-204, src/parser.cpp:1020-1067) */
 typedef struct rt_plane {
     float point[3];
-    float normal[3];
+    float normal[3];       /* transformed and normalised */
+    float raw_normal_x;    /* x of the normal as written in the scene file: the reference's helper-axis choices for
+                              plane texture coordinates, tangents and hemisphere bases read this value, because its
+                              vec3 keeps the parsed scalars next to the transformed SIMD value (src/shapes.cpp:533,554,
+                              src/ray_trace.cpp:45) */
     int32_t material;
     int32_t tex_offset;
     int32_t tex_count;

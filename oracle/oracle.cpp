@@ -431,7 +431,7 @@ struct Tracer {
         }
         const rt_plane &pl = S.planes[h.shape - ntri - nsph];
         V n = mk(pl.normal);
-        V helper = fabsf(n.x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+        V helper = fabsf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);   // reads the parsed scalar, see rt_plane
         V tangent = normalize(cross(n, helper));
         V bitangent = cross(n, tangent);
         V to = sub(p, mk(pl.point));
@@ -459,15 +459,14 @@ struct Tracer {
             return normalize(xdir(in.model, lt));
         }
         if (h.shape < ntri + nsph) {
+            // src/shapes.cpp:473-487 reads the scalar copies of a SIMD-only difference vector, which are still
+            // zero, so the object-space tangent is always (1, 0, 0)
             const rt_sphere &s = S.spheres[h.shape - ntri];
-            V q = sub(xpoint(s.inv_model, p), mk(s.center));
-            float tx = -q.z, tz = q.x;
-            V lt = (tx == 0.0f && tz == 0.0f) ? mk(1, 0, 0) : mk(tx, 0, tz);
-            return normalize(xdir(s.model, lt));
+            return normalize(xdir(s.model, mk(1, 0, 0)));
         }
-        V n = mk(S.planes[h.shape - ntri - nsph].normal);
-        V helper = fabsf(n.x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
-        return normalize(cross(n, helper));
+        const rt_plane &pl = S.planes[h.shape - ntri - nsph];
+        V helper = fabsf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+        return normalize(cross(mk(pl.normal), helper));
     }
 
     // ---- textures (src/texture.cpp) ------------------------------------------------------------
@@ -900,8 +899,9 @@ struct Tracer {
                 float cos_t = 1.0f - 2.0f * rv;
                 float sin_t = sqrtf(fmax_(0.0f, 1.0f - cos_t * cos_t));
                 V unit = mk(sin_t * om::cosf_(phi), sin_t * om::sinf_(phi), cos_t);
-                V local = add(mk(s.center), scl(unit, s.radius));
-                V sp = xpoint(s.model, local);
+                // src/lights.cpp:418-422: the sampled surface point exists only in SIMD lanes; mult_vec reloads its
+                // operand from the (still zero) scalar copies, so the position used is model * (0,0,0,1)
+                V sp = xpoint(s.model, mk(0, 0, 0));
                 V nl = normalize(xdir(s.normal, unit));
                 V du = sub(sp, p);
                 float d2 = dot(du, du);
@@ -1103,16 +1103,30 @@ struct Tracer {
     }
 
     // ---- path tracer, ray_tracer::path_trace src/ray_trace.cpp:871-1139 ---------------------------
-    V path_trace(V o, V d, float time, bool culling, int depth, uint32_t key) {
+    // `diffuse_bounce`: the ray direction came out of sample_*_hemisphere, whose result lives only in SIMD lanes;
+    // the environment lookup of a miss reads the direction's scalar copies (src/ray_trace.cpp:10-12), which are
+    // still (0,0,0) for such rays, so every diffuse-bounce miss fetches the same texel: atan2(+0,-0) = pi gives
+    // u = 1, acos(0)/pi gives v = 1/2 (lat-long); the probe mapping gives (1/2, 1/2).
+    V path_trace(V o, V d, float time, bool culling, int depth, uint32_t key, bool diffuse_bounce = false) {
         V color = mk(0, 0, 0);
         Hit h = intersect(o, d, time, culling, S.d.intersection_epsilon, false, 1e30f);   // default stop_t, src/bvh.h:47
-        if (!h.hit) return background(d, false, 0.f, 0.f);
+        if (!h.hit) {
+            if (diffuse_bounce && S.d.background_texture >= 0 && S.textures[S.d.background_texture].image >= 0) {
+                V c = mk(0, 0, 0);
+                tex_sample(S.textures[S.d.background_texture], S.d.is_probe ? 0.5f : 1.0f, 0.5f, mk(0, 0, 0), c);
+                return c;
+            }
+            return background(d, false, 0.f, 0.f);
+        }
         ++cnt.shaded;
         const rt_material &m = material_of(h);
         color = add(color, emission_of(h));
         V p = add(o, scl(d, h.t));
         V normal = normal_of(h, p);
-        const float helper_x = normal.x;   // the scalar copy that get_orthonormal_basis reads (:45)
+        // the scalar copy that get_orthonormal_basis reads (:45): the geometric normal, or for planes the parsed one
+        const float helper_x = h.shape >= (int)(S.triangles.size() + S.spheres.size())
+                                   ? S.planes[h.shape - (int)(S.triangles.size() + S.spheres.size())].raw_normal_x
+                                   : normal.x;
         int toff, tcount;
         textures_of(h, toff, tcount);
         apply_normal_map(h, p, toff, tcount, normal);
@@ -1198,7 +1212,7 @@ struct Tracer {
                                       helper_x, wi, pdf);
                 V no = add(p, scl(normal, seps));
                 ++cnt.secondary;
-                V bounce = path_trace(no, wi, time, culling, depth + 1, child_key(key, BRANCH_BOUNCE + i));
+                V bounce = path_trace(no, wi, time, culling, depth + 1, child_key(key, BRANCH_BOUNCE + i), true);
                 float ndotl = fmax_(dot(normal, wi), 0.0f);
                 if (pdf > 1e-6f) {
                     V fr = scl(kd, 1.0f / 3.14159265359f);

@@ -28,7 +28,7 @@ class Sphere(C.Structure):
 
 
 class Plane(C.Structure):
-    _fields_ = [("point", F3), ("normal", F3), ("material", i32), ("tex_offset", i32), ("tex_count", i32)]
+    _fields_ = [("point", F3), ("normal", F3), ("raw_normal_x", f32), ("material", i32), ("tex_offset", i32), ("tex_count", i32)]
 
 
 class Image(C.Structure):

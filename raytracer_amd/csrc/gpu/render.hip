@@ -336,7 +336,7 @@ __device__ void uv_of(const DevScene &S, const Surface &s, V p, float &u, float 
     }
     const rt_plane &pl = S.planes[s.index];
     V n = mk(pl.normal);
-    V helper = absf(n.x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
     V tangent = normalize(cross(n, helper));
     V bitangent = cross(n, tangent);
     V to = sub(p, mk(pl.point));
@@ -364,15 +364,13 @@ __device__ V tangent_of(const DevScene &S, const Surface &s, V p) {
         return normalize(xdir(in.model, lt));
     }
     if (s.kind == 1) {
-        const rt_sphere &sp = S.spheres[s.index];
-        V q = sub(xpoint(sp.inv_model, p), mk(sp.center));
-        float tx = -q.z, tz = q.x;
-        V lt = (tx == 0.0f && tz == 0.0f) ? mk(1, 0, 0) : mk(tx, 0, tz);
-        return normalize(xdir(sp.model, lt));
+        // the reference's object-space sphere tangent is always (1, 0, 0): src/shapes.cpp:473-487 reads scalar
+        // copies of a difference vector that only exists in SIMD lanes
+        return normalize(xdir(S.spheres[s.index].model, mk(1, 0, 0)));
     }
-    V n = mk(S.planes[s.index].normal);
-    V helper = absf(n.x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
-    return normalize(cross(n, helper));
+    const rt_plane &pl = S.planes[s.index];
+    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+    return normalize(cross(mk(pl.normal), helper));
 }
 
 // ---- textures (src/texture.cpp) ------------------------------------------------------------------
@@ -797,8 +795,9 @@ __device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal
             float cos_t = 1.0f - 2.0f * rv;
             float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
             V unit = mk(sin_t * rt_cos(phi), sin_t * rt_sin(phi), cos_t);
-            V local = add(mk(s.center), scl(unit, s.radius));
-            V sp = xpoint(s.model, local);
+            // the reference transforms the scalar copies of the sampled point, which are still zero
+            // (src/lights.cpp:418-422): the position used is model * (0,0,0,1)
+            V sp = xpoint(s.model, mk(0, 0, 0));
             V nl = normalize(xdir(s.normal, unit));
             V du = sub(sp, p);
             float d2 = dot(du, du);
@@ -960,7 +959,7 @@ __device__ void camera_sample(const rt_camera_desc &cam, int i, int j, int s, in
 struct PathItem {
     V o, d, thr;
     uint32_t key;
-    int depth_flags;   // depth | culling << 16
+    int depth_flags;   // depth | culling << 16 | diffuse bounce << 17
 };
 
 struct LaunchParams {
@@ -1017,7 +1016,8 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
             while (top >= 0) {
                 const PathItem it = stack[top--];
                 const int depth = it.depth_flags & 0xffff;
-                const bool culling = (it.depth_flags >> 16) != 0;
+                const bool culling = ((it.depth_flags >> 16) & 1) != 0;
+                const bool diffuse_bounce = ((it.depth_flags >> 17) & 1) != 0;
                 const V o = it.o, d = it.d, thr = it.thr;
                 const uint32_t key = it.key;
                 if (!pt && (float)depth >= S.max_depth) {   // Whitted depth limit returns the background (:649-679)
@@ -1026,7 +1026,16 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                 }
                 const Hit h = traverse<false, COUNT>(S, o, d, time, culling, S.ieps, 1e30f, c);
                 if (h.prim == -1) {
-                    sample = add(sample, mul(thr, background(S, cam, d, !pt, pixelu, pixelv, c)));
+                    // A diffuse-bounce miss under an environment map always fetches one fixed texel: the reference
+                    // reads scalar copies of the sampled direction that are still zero (src/ray_trace.cpp:10-12,1093-1116),
+                    // which maps to (u, v) = (1, 1/2) lat-long or (1/2, 1/2) probe.
+                    if (diffuse_bounce && S.bg_tex >= 0 && S.textures[S.bg_tex].image >= 0) {
+                        V bgc = mk(0, 0, 0);
+                        tex_sample(S, S.textures[S.bg_tex], S.is_probe ? 0.5f : 1.0f, 0.5f, mk(0, 0, 0), bgc, c);
+                        sample = add(sample, mul(thr, bgc));
+                    } else {
+                        sample = add(sample, mul(thr, background(S, cam, d, !pt, pixelu, pixelv, c)));
+                    }
                     continue;
                 }
                 ++c.shaded;
@@ -1034,7 +1043,7 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                 const rt_material &m = S.materials[sf.material];
                 V p = add(o, scl(d, h.t));
                 V normal = normal_of(S, sf, p);
-                const float helper_x = normal.x;
+                const float helper_x = sf.kind == 2 ? S.planes[sf.index].raw_normal_x : normal.x;
                 apply_normal_map(S, sf, p, normal, c);
                 apply_bump_map(S, sf, p, normal, c);
                 const float seps = S.seps;
@@ -1209,7 +1218,7 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                         n.d = wi;
                         n.thr = mul(thr, w);
                         n.key = child_key(key, BRANCH_BOUNCE + b);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16);
+                        n.depth_flags = (depth + 1) | ((int)culling << 16) | (1 << 17);
                     }
                 }
             }

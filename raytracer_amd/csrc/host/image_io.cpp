@@ -330,14 +330,6 @@ void png_chunk(std::vector<uint8_t> &out, const char *type, const std::vector<ui
     put_be32(out, crc_of(&out[start], out.size() - start));
 }
 
-bool has_suffix(const std::string &s, const char *suf) {
-    size_t n = strlen(suf);
-    if (s.size() < n) return false;
-    for (size_t i = 0; i < n; ++i)
-        if (tolower((unsigned char)s[s.size() - n + i]) != suf[i]) return false;
-    return true;
-}
-
 }  // namespace
 
 bool load_image_file(const std::string &path, HostScene &scene, rt_image &out, std::string &err) {

@@ -856,7 +856,9 @@ bool load_scene(const std::string &json_path, HostScene &out, std::string &err) 
         M4 model = compose_transformations(pl, tt);
         put3(p.point, xform_point(model, point));
         M4 nm = transpose(inverse(model));
-        put3(p.normal, normalize(xform_dir(nm, vec3_of(pl["Normal"]))));
+        V3 raw_normal = vec3_of(pl["Normal"]);
+        put3(p.normal, normalize(xform_dir(nm, raw_normal)));
+        p.raw_normal_x = raw_normal.x;
         if (!material_index(pl, p.material)) {
             ok = false;
             return;

@@ -29,15 +29,6 @@ std::string lower(std::string s) {
     return s;
 }
 
-// byte width of a scalar PLY type, 0 if unknown
-int type_size(const std::string &t) {
-    if (t == "float" || t == "float32" || t == "int" || t == "int32" || t == "uint" || t == "uint32") return 4;
-    if (t == "double" || t == "float64") return 8;
-    if (t == "uchar" || t == "uint8" || t == "char" || t == "int8") return 1;
-    if (t == "ushort" || t == "uint16" || t == "short" || t == "int16") return 2;
-    return 0;
-}
-
 struct Cursor {
     const unsigned char *p, *end;
     bool take(void *dst, size_t n) {
