@@ -14,14 +14,18 @@
 // launch geometry, sharding or scheduling, and sample sums are taken in the reference's order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "gpu_render.h"
 #include "rt_math.h"
+#include "rt_device.h"
 
 using namespace rt;
 
@@ -38,937 +42,80 @@ thread_local std::string g_error;
         }                                                                                             \
     } while (0)
 
-constexpr int TILE = 32;              // image tile edge used for sharding
-constexpr int BLOCK_EDGE = 16;        // pixels per workgroup edge
-constexpr int PATH_STACK = 24;        // pending rays per lane
-constexpr int TRAVERSAL_STACK = 64;   // src/bvh.cpp:423
+// =====================================================================================================
+// Wavefront pipeline.
+//
+// A frame is rendered in batches of camera samples ("slots").  Per batch:
+//   generate  camera rays of the batch's (pixel, sample) pairs              -> path queue 0
+//   repeat    closest   closest-hit BVH traversal of every queued path       -> hit records
+//             shade     material / texture / emission / roulette; appends direct-lighting work
+//                       (vertex records) and child paths, compacted with wave ballots -> path queue 1
+//             direct    one lane per (vertex, light sample): light sampling, any-hit shadow
+//                       traversal, BRDF, fixed-order reduction over the vertex's lanes
+//   resolve   per pixel: clamp each sample, sum the samples in index order, divide
+// The recursion of the reference (trace_rec / path_trace) becomes the loop over queue generations; a
+// path carries its throughput, so the order in which paths are processed does not change what is
+// added to a slot, and a slot's random numbers depend only on (seed, pixel, sample, path node).
+// =====================================================================================================
 
-enum {
-    DIM_REFLECT_XI1 = 0, DIM_REFLECT_XI2 = 1, DIM_REFRACT_XI1 = 2, DIM_REFRACT_XI2 = 3, DIM_RR = 4, DIM_HEMI_1 = 5, DIM_HEMI_2 = 6,
-    DIM_SPLIT = 8, DIM_LIGHT = 4096,
-    DIM_CAM_R1 = 0, DIM_CAM_R2 = 1, DIM_CAM_R3 = 2, DIM_CAM_R4 = 3, DIM_CAM_TIME = 4,
-    BRANCH_ROOT = 0, BRANCH_REFLECT = 1, BRANCH_REFRACT = 2, BRANCH_BOUNCE = 3
+constexpr int MAX_GENERATIONS = 66;   // queue generations per batch (depth limit + 2)
+
+struct PathQueue {
+    float4 *o_time;     // origin.xyz, ray time
+    float4 *d_key;      // direction.xyz, bits(path-node key)
+    float4 *thr_slot;   // throughput.xyz, bits(slot)
+    int *depth_flags;   // depth | culling << 16 | diffuse bounce << 17
 };
 
-// ---- device-resident scene -------------------------------------------------------------------
-// nodes:  2 x float4 per BVH node  {bmin.xyz, bits(offset)} {bmax.xyz, bits(n_prims | axis << 16)}
-// prims:  3 x float4 per leaf entry, in leaf order:
-//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), bits(shape), bits(ref id)}
-//         sphere   {...unused...}                 {0, bits(-1 - sphere), bits(shape), bits(123456)}
-// inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
-//         flags bit0 = identity transform, bit1 = has motion blur
-struct DevScene {
-    const float4 *nodes;
-    const float4 *prims;
-    const float4 *inst;
-    const rt_instance *instances;
-    const rt_triangle *triangles;
-    const float *flat_normals;
-    const rt_sphere *spheres;
-    const rt_plane *planes;
-    const rt_material *materials;
-    const rt_texture *textures;
-    const int32_t *texture_refs;
-    const rt_image *images;
-    const uint8_t *texels_u8;
-    const float *texels_f32;
-    const rt_light *lights;
-    int n_triangles, n_spheres, n_planes, n_lights, n_nodes;
-    float ieps, seps, max_depth;
-    float ambient[3], bg[3];
-    int bg_tex, is_probe;
+struct VertexBuf {      // one record per shading point that needs direct lighting
+    float4 *p_time;     // position.xyz, ray time
+    float4 *n_key;      // shading normal.xyz, bits(key)
+    float4 *view_mat;   // unit vector towards the ray origin .xyz, bits(material index)
+    float4 *kd_slot;    // diffuse reflectance after textures .xyz, bits(slot)
+    float4 *ks_w;       // specular reflectance after textures .xyz, (unused)
+    float4 *weight;     // path throughput x LDR scale .xyz, (unused)
 };
 
-struct Counters {   // per-lane, reduced per wave at kernel end
-    uint32_t primary, shadow, secondary, shaded;
-    uint32_t nodes, tri, sph, pln, texels;
+struct Wavefront {
+    PathQueue q[2];
+    float *hit_t;
+    int *hit_prim;
+    VertexBuf vtx;
+    float *accum;             // 3 floats per slot
+    unsigned *path_count;     // [MAX_GENERATIONS + 1] entries per generation
+    unsigned *vertex_count;   // [MAX_GENERATIONS + 1]
+    unsigned *overflow;       // set when a queue ran out of room
+    unsigned capacity;        // entries per queue / vertex buffer
 };
 
-struct Hit {
-    float t;
-    int prim;   // >= 0 leaf entry; <= -2 plane (-2 - index); -1 none
+struct Batch {
+    int tile_first, tile_count;   // range in this rank's list of owned tiles
+    int n_pixels;                 // tile_count * 1024 (pixel-local indices, including out-of-image ones)
+    int n_samples, grid_n;
+    int tiles_x;
+    int rank, world;
 };
 
-// ---- traversal ---------------------------------------------------------------------------------
-// bvh::intersect (src/bvh.cpp:383-480) with intersect_aabb_fast (:348-381): planes first, then an
-// ordered stack traversal (near child first by the sign of the ray direction on the split axis).
-// A hit replaces the current one only if t > eps and t < t_hit, so of equal-distance hits the one
-// found first in this order is kept.
-template <bool ANY, bool COUNT>
-__device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, float eps, float stop_t, Counters &c) {
-    Hit h;
-    h.t = stop_t;
-    h.prim = -1;
-    for (int pi = 0; pi < S.n_planes; ++pi) {   // plane::intersect, src/shapes.cpp:506-527
-        if (COUNT) ++c.pln;
-        const rt_plane &p = S.planes[pi];
-        V n = mk(p.normal);
-        float denom = dot(n, d);
-        if (absf(denom) < eps) continue;
-        float num = dot(sub(mk(p.point), o), n);
-        float tc = rt_div(num, denom);
-        if (tc < eps) continue;
-        if (tc > eps && tc < h.t) {
-            h.t = tc;
-            h.prim = -2 - pi;
-            if (ANY) return h;
-        }
-    }
-    if (S.n_nodes == 0) return h;
-    const float ix = rt_div(1.0f, d.x), iy = rt_div(1.0f, d.y), iz = rt_div(1.0f, d.z);
-    const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
-    int stack[TRAVERSAL_STACK];
-    int top = 0;
-    stack[0] = 0;
-    int cur_inst = -1;   // placement whose object-space ray is cached in oo/dd
-    V oo = o, dd = d;
-    while (top >= 0) {
-        const int ni = stack[top--];
-        const float4 n0 = S.nodes[2 * ni], n1 = S.nodes[2 * ni + 1];
-        if (COUNT) ++c.nodes;
-        float tmin = ((nx ? n1.x : n0.x) - o.x) * ix;
-        float tmax = ((nx ? n0.x : n1.x) - o.x) * ix;
-        const float tymin = ((ny ? n1.y : n0.y) - o.y) * iy;
-        const float tymax = ((ny ? n0.y : n1.y) - o.y) * iy;
-        if ((tmin > tymax) || (tymin > tmax)) continue;
-        if (tymin > tmin) tmin = tymin;
-        if (tymax < tmax) tmax = tymax;
-        const float tzmin = ((nz ? n1.z : n0.z) - o.z) * iz;
-        const float tzmax = ((nz ? n0.z : n1.z) - o.z) * iz;
-        if ((tmin > tzmax) || (tzmin > tmax)) continue;
-        if (tzmin > tmin) tmin = tzmin;
-        if (tzmax < tmax) tmax = tzmax;
-        if (!((tmin < h.t) && (tmax > 0.0f))) continue;
-        const int offset = __float_as_int(n0.w);
-        const int meta = __float_as_int(n1.w);
-        const int nprims = meta & 0xffff;
-        if (nprims > 0) {
-            for (int i = 0; i < nprims; ++i) {
-                const int k = offset + i;
-                const float4 p2 = S.prims[3 * k + 2];
-                const int inst = __float_as_int(p2.y);
-                float tc;
-                if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
-                    if (COUNT) ++c.tri;
-                    const float4 p0 = S.prims[3 * k], p1 = S.prims[3 * k + 1];
-                    if (inst != cur_inst) {
-                        cur_inst = inst;
-                        const float4 r3 = S.inst[4 * inst + 3];
-                        const int flags = __float_as_int(r3.w);
-                        V moved = o;
-                        if (flags & 2) moved = sub(o, scl(mk(r3.x, r3.y, r3.z), time));
-                        if (flags & 1) {
-                            oo = moved;
-                            dd = d;
-                        } else {
-                            const float4 r0 = S.inst[4 * inst], r1 = S.inst[4 * inst + 1], r2 = S.inst[4 * inst + 2];
-                            oo = mk((r0.x * moved.x + r0.y * moved.y) + (r0.z * moved.z + r0.w),
-                                    (r1.x * moved.x + r1.y * moved.y) + (r1.z * moved.z + r1.w),
-                                    (r2.x * moved.x + r2.y * moved.y) + (r2.z * moved.z + r2.w));
-                            dd = mk((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z,
-                                    (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
-                        }
-                    }
-                    const V c1s = mk(p0.x, p0.y, p0.z), e1 = mk(p0.w, p1.x, p1.y), e2 = mk(p1.z, p1.w, p2.x);
-                    const V os = scl(oo, 1000.0f);
-                    const V hh = cross(dd, e2);
-                    const float det = dot(e1, hh);
-                    if (culling) {
-                        if (det < eps) continue;
-                    } else {
-                        if (absf(det) < eps) continue;
-                    }
-                    const float f = rt_div(1.0f, det);
-                    const V s = sub(os, c1s);
-                    float u = dot(s, hh);
-                    u *= f;
-                    if (u < (0.0f - eps) || u > (1.0f + eps)) continue;
-                    const V q = cross(s, e1);
-                    float v = dot(dd, q);
-                    v *= f;
-                    if (v < (0.0f - eps) || (u + v) > (1.0f + eps)) continue;
-                    tc = dot(e2, q);
-                    tc *= f;
-                    tc *= (1.0f / 1000.0f);
-                    if (!(tc > eps)) continue;
-                } else {   // sphere::intersect, src/shapes.cpp:407-447
-                    if (COUNT) ++c.sph;
-                    const rt_sphere &sp = S.spheres[-1 - inst];
-                    const V so = xpoint(sp.inv_model, o);
-                    const V sd = xdir(sp.inv_model, d);
-                    const V oc = sub(so, mk(sp.center));
-                    const float a = dot(sd, sd);
-                    float b = dot(oc, sd);
-                    b *= 2.0f;
-                    float cc = dot(oc, oc);
-                    cc -= (sp.radius * sp.radius);
-                    const float disc = b * b - 4 * a * cc;
-                    if (disc < 0.0f) continue;
-                    const float sq = rt_sqrt(disc);
-                    const float inv2a = rt_div(1.0f, 2.0f * a);
-                    const float t1 = (-b - sq) * inv2a, t2 = (-b + sq) * inv2a;
-                    if (t1 > eps)
-                        tc = t1;
-                    else if (t2 > eps)
-                        tc = t2;
-                    else
-                        continue;
-                }
-                if (tc > eps && tc < h.t) {
-                    h.t = tc;
-                    h.prim = k;
-                    if (ANY) return h;
-                }
-            }
-        } else {
-            const int axis = meta >> 16;
-            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            const int near_i = neg ? offset : ni + 1;
-            const int far_i = neg ? ni + 1 : offset;
-            stack[++top] = far_i;
-            stack[++top] = near_i;
-        }
-    }
-    return h;
+__device__ __forceinline__ void batch_pixel(const Batch &b, int pl, int &i, int &j) {
+    const int tile = (b.tile_first + (pl >> 10)) * b.world + b.rank;
+    const int tx = tile % b.tiles_x, ty = tile / b.tiles_x;
+    const int in = pl & 1023, quad = in >> 8, wave = (in >> 6) & 3, lane = in & 63;
+    i = tx * TILE + (quad & 1) * 16 + (wave & 1) * 8 + (lane & 7);
+    j = ty * TILE + (quad >> 1) * 16 + (wave >> 1) * 8 + (lane >> 3);
 }
 
-// ---- hit decoding -----------------------------------------------------------------------------
-struct Surface {
-    int kind;       // 0 triangle, 1 sphere, 2 plane
-    int index;      // triangle / sphere / plane index
-    int instance;   // placement (triangles)
-    int material;
-    int toff, tcount;
-};
-
-__device__ Surface surface_of(const DevScene &S, const Hit &h) {
-    Surface s;
-    if (h.prim <= -2) {
-        s.kind = 2;
-        s.index = -2 - h.prim;
-        s.instance = -1;
-        const rt_plane &p = S.planes[s.index];
-        s.material = p.material;
-        s.toff = p.tex_offset;
-        s.tcount = p.tex_count;
-        return s;
-    }
-    const float4 p2 = S.prims[3 * h.prim + 2];
-    const int inst = __float_as_int(p2.y);
-    if (inst >= 0) {
-        s.kind = 0;
-        s.index = __float_as_int(p2.z);
-        s.instance = inst;
-        const rt_instance &in = S.instances[inst];
-        s.material = in.material;
-        s.toff = in.tex_offset;
-        s.tcount = in.tex_count;
-    } else {
-        s.kind = 1;
-        s.index = -1 - inst;
-        s.instance = -1;
-        const rt_sphere &sp = S.spheres[s.index];
-        s.material = sp.material;
-        s.toff = sp.tex_offset;
-        s.tcount = sp.tex_count;
-    }
-    return s;
+// Wave-aggregated append: lanes with `want` get consecutive indices from *counter (one atomic per wave).
+__device__ __forceinline__ unsigned wave_append(bool want, unsigned *counter) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned prefix = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + prefix;
 }
-
-// get_normal: triangle src/shapes.cpp:152-197, sphere :390-405, plane :504
-__device__ V normal_of(const DevScene &S, const Surface &s, V p) {
-    if (s.kind == 0) {
-        const rt_triangle &t = S.triangles[s.index];
-        const rt_instance &in = S.instances[s.instance];
-        if (!t.smooth) return normalize(xdir(in.normal, mk(S.flat_normals + 3 * s.index)));
-        V po = xpoint(in.inv_model, p);
-        V c1 = mk(t.c1);
-        V v0 = sub(mk(t.c2), c1), v1 = sub(mk(t.c3), c1), v2 = sub(po, c1);
-        float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
-        const float denom = d00 * d11 - d01 * d01;
-        float v = rt_div(d11 * d20 - d01 * d21, denom);
-        float w = rt_div(d00 * d21 - d01 * d20, denom);
-        float u = 1.0f - v - w;
-        V n = add(add(scl(mk(t.n1), u), scl(mk(t.n2), v)), scl(mk(t.n3), w));
-        n = normalize(n);
-        return normalize(xdir(in.normal, n));
-    }
-    if (s.kind == 1) {
-        const rt_sphere &sp = S.spheres[s.index];
-        V po = xpoint(sp.inv_model, p);
-        return normalize(xdir(sp.normal, sub(po, mk(sp.center))));
-    }
-    return mk(S.planes[s.index].normal);
-}
-
-// calculate_uv: triangle src/shapes.cpp:87-122, sphere :449-465, plane :529-548
-__device__ void uv_of(const DevScene &S, const Surface &s, V p, float &u, float &v) {
-    if (s.kind == 0) {
-        const rt_triangle &t = S.triangles[s.index];
-        const rt_instance &in = S.instances[s.instance];
-        V local = xpoint(in.inv_model, p);
-        V c1 = mk(t.c1);
-        V e1 = sub(mk(t.c2), c1), e2 = sub(mk(t.c3), c1), vp = sub(local, c1);
-        float d00 = dot(e1, e1), d01 = dot(e1, e2), d11 = dot(e2, e2), d20 = dot(vp, e1), d21 = dot(vp, e2);
-        float denom = d00 * d11 - d01 * d01;
-        if (absf(denom) < 1e-10f) {
-            u = 0.0f;
-            v = 0.0f;
-            return;
-        }
-        float inv = rt_div(1.0f, denom);
-        float beta = (d11 * d20 - d01 * d21) * inv;
-        float gamma = (d00 * d21 - d01 * d20) * inv;
-        float alpha = 1.0f - beta - gamma;
-        u = alpha * t.tex_u[0] + beta * t.tex_u[1] + gamma * t.tex_u[2];
-        v = alpha * t.tex_v[0] + beta * t.tex_v[1] + gamma * t.tex_v[2];
-        return;
-    }
-    if (s.kind == 1) {
-        const rt_sphere &sp = S.spheres[s.index];
-        V q = normalize(sub(xpoint(sp.inv_model, p), mk(sp.center)));
-        float phi = rt_atan2(q.z, q.x);
-        float theta = rt_asin(q.y);
-        const float PI = 3.14159265359f;
-        u = 1.0f - rt_div(phi + PI, 2.0f * PI);
-        v = 1.0f - rt_div(theta + PI / 2.0f, PI);
-        return;
-    }
-    const rt_plane &pl = S.planes[s.index];
-    V n = mk(pl.normal);
-    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
-    V tangent = normalize(cross(n, helper));
-    V bitangent = cross(n, tangent);
-    V to = sub(p, mk(pl.point));
-    u = dot(to, tangent);
-    v = dot(to, bitangent);
-}
-
-// get_tangent: triangle src/shapes.cpp:281-316, sphere :467-494, plane :550-562
-__device__ V tangent_of(const DevScene &S, const Surface &s, V p) {
-    if (s.kind == 0) {
-        const rt_triangle &t = S.triangles[s.index];
-        const rt_instance &in = S.instances[s.instance];
-        V c1 = mk(t.c1);
-        V e1 = sub(mk(t.c2), c1), e2 = sub(mk(t.c3), c1);
-        float du1 = t.tex_u[1] - t.tex_u[0], dv1 = t.tex_v[1] - t.tex_v[0];
-        float du2 = t.tex_u[2] - t.tex_u[0], dv2 = t.tex_v[2] - t.tex_v[0];
-        float det = (du1 * dv2 - du2 * dv1);
-        V lt;
-        if (absf(det) < 1e-8f) {
-            lt = e1;
-        } else {
-            float f = rt_div(1.0f, det);
-            lt = scl(sub(scl(e1, dv2), scl(e2, dv1)), f);
-        }
-        return normalize(xdir(in.model, lt));
-    }
-    if (s.kind == 1) {
-        // the reference's object-space sphere tangent is always (1, 0, 0): src/shapes.cpp:473-487 reads scalar
-        // copies of a difference vector that only exists in SIMD lanes
-        return normalize(xdir(S.spheres[s.index].model, mk(1, 0, 0)));
-    }
-    const rt_plane &pl = S.planes[s.index];
-    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
-    return normalize(cross(mk(pl.normal), helper));
-}
-
-// ---- textures (src/texture.cpp) ------------------------------------------------------------------
-__device__ bool image_sample(const DevScene &S, const rt_image &im, bool bilinear, float u, float v, V &color, Counters &c) {
-    if (im.width <= 0 || im.height <= 0) return false;
-    const int W = im.width, H = im.height;
-    u -= floorf(u);
-    v -= floorf(v);
-    if (!bilinear) {   // image::sample_nearest :64-93
-        int x = (int)(u * W), y = (int)(v * H);
-        if (x >= W) x = W - 1;
-        if (y >= H) y = H - 1;
-        ++c.texels;
-        if (im.is_hdr) {
-            const float *p = S.texels_f32 + (size_t)im.offset + ((size_t)y * W + x) * 4;
-            color = mk(p[0], p[1], p[2]);
-        } else {
-            const uint8_t *p = S.texels_u8 + (size_t)im.offset + ((size_t)y * W + x) * 3;
-            color = mk(p[0] * (1.0f / 255.0f), p[1] * (1.0f / 255.0f), p[2] * (1.0f / 255.0f));
-        }
-        return true;
-    }
-    // image::sample_bilinear :95-166
-    float px = u * W - 0.5f, py = v * H - 0.5f;
-    int x = (int)floorf(px), y = (int)floorf(py);
-    float ur = px - x, vr = py - y;
-    float uo = 1.0f - ur, vo = 1.0f - vr;
-    int x0 = (x % W + W) % W, x1 = ((x + 1) % W + W) % W;
-    int y0 = (y % H + H) % H, y1 = ((y + 1) % H + H) % H;
-    c.texels += 4;
-    float out[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        float v00, v10, v01, v11;
-        if (im.is_hdr) {
-            const float *b = S.texels_f32 + (size_t)im.offset;
-            v00 = b[((size_t)y0 * W + x0) * 4 + ch];
-            v10 = b[((size_t)y0 * W + x1) * 4 + ch];
-            v01 = b[((size_t)y1 * W + x0) * 4 + ch];
-            v11 = b[((size_t)y1 * W + x1) * 4 + ch];
-        } else {
-            const uint8_t *b = S.texels_u8 + (size_t)im.offset;
-            v00 = b[((size_t)y0 * W + x0) * 3 + ch];
-            v10 = b[((size_t)y0 * W + x1) * 3 + ch];
-            v01 = b[((size_t)y1 * W + x0) * 3 + ch];
-            v11 = b[((size_t)y1 * W + x1) * 3 + ch];
-        }
-        float top = v00 * uo + v10 * ur;
-        float bot = v01 * uo + v11 * ur;
-        out[ch] = top * vo + bot * vr;
-    }
-    if (im.is_hdr)
-        color = mk(out[0], out[1], out[2]);
-    else
-        color = mk(out[0] * (1.0f / 255.0f), out[1] * (1.0f / 255.0f), out[2] * (1.0f / 255.0f));
-    return true;
-}
-
-__constant__ uint8_t PERLIN_P[256] = {   // Ken Perlin's reference permutation (src/texture.cpp:238)
-    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,  37,  240,
-    21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,  57,  177, 33,  88,
-    237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111,
-    229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,
-    209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217,
-    226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,
-    223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,
-    108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241,
-    81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,
-    150, 254, 138, 236, 205, 93,  222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
-
-__device__ __forceinline__ float pfade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }
-__device__ __forceinline__ float plerp(float t, float a, float b) { return a + t * (b - a); }
-__device__ __forceinline__ float pgrad(int hash, float x, float y, float z) {
-    int h = hash & 15;
-    float u = h < 8 ? x : y;
-    float v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
-    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
-}
-__device__ float perlin_noise(float x, float y, float z) {   // Perlin::noise :204-223
-    auto p = [](int i) -> int { return PERLIN_P[i & 255]; };
-    int X = (int)floorf(x) & 255, Y = (int)floorf(y) & 255, Z = (int)floorf(z) & 255;
-    x -= floorf(x);
-    y -= floorf(y);
-    z -= floorf(z);
-    float u = pfade(x), v = pfade(y), w = pfade(z);
-    int A = p(X) + Y, AA = p(A) + Z, AB = p(A + 1) + Z;
-    int B = p(X + 1) + Y, BA = p(B) + Z, BB = p(B + 1) + Z;
-    return plerp(w,
-                 plerp(v, plerp(u, pgrad(p(AA), x, y, z), pgrad(p(BA), x - 1, y, z)),
-                       plerp(u, pgrad(p(AB), x, y - 1, z), pgrad(p(BB), x - 1, y - 1, z))),
-                 plerp(v, plerp(u, pgrad(p(AA + 1), x, y, z - 1), pgrad(p(BA + 1), x - 1, y, z - 1)),
-                       plerp(u, pgrad(p(AB + 1), x, y - 1, z - 1), pgrad(p(BB + 1), x - 1, y - 1, z - 1))));
-}
-__device__ float perlin(V h, const rt_texture &t) {   // perlin() :241-274
-    float s = 0.0f;
-    float x = h.x * t.noise_scale, y = h.y * t.noise_scale, z = h.z * t.noise_scale;
-    float weight = 1.0f, max_amp = 0.0f;
-    int K = (int)t.num_octaves;
-    if (K < 1) K = 1;
-    for (int k = 0; k < K; ++k) {
-        s += weight * perlin_noise(x, y, z);
-        max_amp += weight;
-        x *= 2.0f;
-        y *= 2.0f;
-        weight *= 0.5f;
-    }
-    float sn = rt_div(s, max_amp);
-    if (t.noise_conversion == RT_NOISE_ABSVAL) return absf(sn);
-    return (sn + 1.0f) * 0.5f;
-}
-// texture::sample :168-197
-__device__ void tex_sample(const DevScene &S, const rt_texture &t, float u, float v, V h, V &color, Counters &c) {
-    if (t.image >= 0) {
-        image_sample(S, S.images[t.image], t.interp != RT_INTERP_NEAREST, u, v, color, c);
-    } else if (t.kind == RT_TEX_CHECKER) {
-        int x = (int)floorf((u + t.offset) * t.scale);
-        int y = (int)floorf((v + t.offset) * t.scale);
-        color = ((x + y) % 2 != 0) ? mk(t.black) : mk(t.white);
-    } else {
-        float x = perlin(h, t);
-        color = mk(x, x, x);
-    }
-}
-
-// get_latlong_uv / get_probe_uv, src/ray_trace.cpp:7-39
-__device__ void latlong_uv(V d, float &u, float &v) {
-    const float pi = 3.14159265359f;
-    u = (1.0f + rt_div(rt_atan2(d.x, -d.z), pi)) * 0.5f;
-    v = rt_div(rt_acos(d.y), pi);
-}
-__device__ void probe_uv(V d, float &u, float &v) {
-    const float pi = 3.14159265359f;
-    float len_sq = d.x * d.x + d.y * d.y;
-    float r = 0.0f;
-    if (len_sq > 1e-6f) r = rt_div((1.0f / pi) * rt_acos(-d.z), rt_sqrt(len_sq));
-    u = (r * d.x + 1.0f) * 0.5f;
-    v = (-r * d.y + 1.0f) * 0.5f;
-}
-// miss / depth-limit colour (src/ray_trace.cpp:649-679, 691-721, 887-903)
-__device__ V background(const DevScene &S, const rt_camera_desc &cam, V dir, bool whitted, float pixelu, float pixelv, Counters &c) {
-    if (S.bg_tex >= 0) {
-        const rt_texture &bg = S.textures[S.bg_tex];
-        if (bg.image >= 0) {
-            V color = mk(0, 0, 0);
-            if (!whitted || cam.is_hdr) {
-                float u, v;
-                if (S.is_probe)
-                    probe_uv(dir, u, v);
-                else
-                    latlong_uv(dir, u, v);
-                tex_sample(S, bg, u, v, mk(0, 0, 0), color, c);
-            } else {
-                tex_sample(S, bg, pixelu, pixelv, mk(pixelu, pixelv, 0), color, c);
-            }
-            return color;
-        }
-    }
-    return mk(S.bg);
-}
-
-// ---- directions (src/ray_trace.cpp:41-105, 408-492) ------------------------------------------------
-__device__ void sample_hemisphere(bool cosine, float r1, float r2, V normal, float helper_x, V &dir, float &pdf) {
-    float phi = 2.0f * 3.14159265359f * r1;
-    float sin_theta, cos_theta;
-    if (cosine) {
-        sin_theta = rt_sqrt(r2);
-        cos_theta = rt_sqrt(1.0f - r2);
-    } else {
-        sin_theta = rt_sqrt(1.0f - r2 * r2);
-        cos_theta = r2;
-    }
-    float x = sin_theta * rt_cos(phi), y = sin_theta * rt_sin(phi), z = cos_theta;
-    V w = normal;
-    V helper = absf(helper_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
-    V u = normalize(cross(helper, w));
-    V v = normalize(cross(w, u));
-    dir = normalize(add(add(scl(u, x), scl(v, y)), scl(w, z)));
-    pdf = cosine ? rt_div(cos_theta, 3.14159265359f) : 1.0f / (2.0f * 3.14159265359f);
-}
-__device__ void add_roughness(V &R, float roughness, float r_xi1, float r_xi2) {
-    float ax = absf(R.x), ay = absf(R.y), az = absf(R.z);
-    V rp;
-    if (ax <= ay && ax <= az)
-        rp = mk(1.0f, R.y, R.z);
-    else if (ay <= az)
-        rp = mk(R.x, 1.0f, R.z);
-    else
-        rp = mk(R.x, R.y, 1.0f);
-    V u = normalize(cross(R, rp));
-    V v = cross(R, u);
-    float xi1 = r_xi1 - 0.5f, xi2 = r_xi2 - 0.5f;
-    V off = scl(add(scl(u, xi1), scl(v, xi2)), roughness);
-    R = add(R, off);
-}
-__device__ V reflect_dir(V N, V I, float roughness, uint32_t key) {
-    float d = dot(I, N);
-    V R = add(I, scl(N, d * -2.0f));
-    if (roughness > 0.0f) add_roughness(R, roughness, rnd(key, DIM_REFLECT_XI1), rnd(key, DIM_REFLECT_XI2));
-    return normalize(R);
-}
-__device__ bool refract_dir(V N, V I, float n1, float n2, float roughness, uint32_t key, V &T) {
-    float cosi = -dot(I, N);
-    float eta = rt_div(n1, n2);
-    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
-    if (k < 0.0f) return false;
-    T = add(scl(I, eta), scl(N, (eta * cosi - rt_sqrt(k))));
-    if (roughness > 0.0f) add_roughness(T, roughness, rnd(key, DIM_REFRACT_XI1), rnd(key, DIM_REFRACT_XI2));
-    T = normalize(T);
-    return true;
-}
-// exact conductor Fresnel reflectance, src/ray_trace.cpp:751-786
-__device__ float conductor_fresnel(float cos_theta, float n, float k) {
-    float c = cos_theta, c2 = c * c, s2 = 1.0f - c2;
-    float n2 = n * n, k2 = k * k, n2_k2 = n2 - k2, n2k2_4 = 4.0f * n2 * k2;
-    float a2_b2 = rt_sqrt((n2_k2 - s2) * (n2_k2 - s2) + n2k2_4);
-    float a2 = 0.5f * (a2_b2 + n2_k2 - s2);
-    float a = rt_sqrt(a2);
-    float b2 = a2_b2 - a2;
-    float b = rt_sqrt(b2);
-    float rs_num = a2_b2 + c2 - (2.0f * a * c);
-    float rs_den = a2_b2 + c2 + (2.0f * a * c);
-    float rs = (rs_den == 0.0f) ? 1.0f : rt_div(rs_num, rs_den);
-    float ac = a * c, bc = b * c;
-    float t1n = ac - s2, t1d = ac + s2;
-    float rp_num = (t1n * t1n) + (bc * bc);
-    float rp_den = (t1d * t1d) + (bc * bc);
-    float rp = (rp_den == 0.0f) ? 1.0f : rs * rt_div(rp_num, rp_den);
-    float F = 0.5f * (rs + rp);
-    return F < 0.0f ? 0.0f : (F > 1.0f ? 1.0f : F);
-}
-
-// ---- normal / bump mapping (src/ray_trace.cpp:494-644) ------------------------------------------------
-__device__ void apply_normal_map(const DevScene &S, const Surface &s, V p, V &normal, Counters &c) {
-    for (int k = 0; k < s.tcount; ++k) {
-        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
-        if (tex.decal_mode != RT_DECAL_REPLACE_NORMAL) continue;
-        float u, v;
-        uv_of(S, s, p, u, v);
-        V raw = mk(0.5f, 0.5f, 1.0f);
-        tex_sample(S, tex, u, v, p, raw, c);
-        V ts = sub(scl(raw, 2.0f), mk(1.0f, 1.0f, 1.0f));
-        V T = tangent_of(S, s, p);
-        float ndott = dot(normal, T);
-        T = normalize(sub(T, scl(normal, ndott)));
-        V B = cross(normal, T);
-        V nn = add(add(scl(T, ts.x), scl(B, ts.y)), scl(normal, ts.z));
-        normal = normalize(nn);
-        return;
-    }
-}
-__device__ void apply_bump_map(const DevScene &S, const Surface &s, V p, V &normal, Counters &c) {
-    for (int k = 0; k < s.tcount; ++k) {
-        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
-        if (tex.decal_mode != RT_DECAL_BUMP_NORMAL) continue;
-        if (tex.image >= 0) {
-            const rt_image &im = S.images[tex.image];
-            float u, v;
-            uv_of(S, s, p, u, v);
-            float du = rt_div(1.0f, (float)im.width), dv = rt_div(1.0f, (float)im.height);
-            V hc = mk(0, 0, 0), hu = mk(0, 0, 0), hv = mk(0, 0, 0);
-            tex_sample(S, tex, u, v, p, hc, c);
-            tex_sample(S, tex, u + du, v, p, hu, c);
-            tex_sample(S, tex, u, v + dv, p, hv, c);
-            float dh_du = (hu.x - hc.x) * tex.bump_factor;
-            float dh_dv = (hv.x - hc.x) * tex.bump_factor;
-            V T = tangent_of(S, s, p);
-            float ndott = dot(normal, T);
-            T = normalize(sub(T, scl(normal, ndott)));
-            V B = cross(normal, T);
-            V nn = sub(sub(normal, scl(T, dh_du)), scl(B, dh_dv));
-            normal = normalize(nn);
-        } else {
-            const float eps = 0.01f;
-            const float inv_eps = 1.0f / eps;
-            V hc, hx, hy, hz;
-            tex_sample(S, tex, 0, 0, p, hc, c);
-            tex_sample(S, tex, 0, 0, add(p, mk(eps, 0, 0)), hx, c);
-            tex_sample(S, tex, 0, 0, add(p, mk(0, eps, 0)), hy, c);
-            tex_sample(S, tex, 0, 0, add(p, mk(0, 0, eps)), hz, c);
-            V g = mk((hx.x - hc.x) * inv_eps, (hy.x - hc.x) * inv_eps, (hz.x - hc.x) * inv_eps);
-            float gdn = dot(g, normal);
-            V surf = sub(g, scl(normal, gdn));
-            normal = normalize(sub(normal, scl(surf, tex.bump_factor)));
-        }
-        return;
-    }
-}
-
-// resolve_textures, src/ray_trace.cpp:107-152.  kd_rr: the diffuse reflectance Russian roulette reads
-// (the reference's blend_kd update does not reach the scalar copies that roulette looks at).
-__device__ void resolve_textures(const DevScene &S, const Surface &s, V p, const rt_material &m, V &kd, V &ks, V &kd_rr,
-                                 bool &replace_all, V &replace_color, Counters &c) {
-    kd = mk(m.diffuse);
-    ks = mk(m.specular);
-    kd_rr = kd;
-    replace_all = false;
-    for (int k = 0; k < s.tcount; ++k) {
-        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
-        float u, v;
-        if (tex.decal_mode == RT_DECAL_REPLACE_KD) {
-            uv_of(S, s, p, u, v);
-            tex_sample(S, tex, u, v, p, kd, c);
-            kd_rr = kd;
-        } else if (tex.decal_mode == RT_DECAL_BLEND_KD) {
-            uv_of(S, s, p, u, v);
-            V tmp = mk(0, 0, 0);
-            tex_sample(S, tex, u, v, p, tmp, c);
-            kd = scl(add(mk(m.diffuse), tmp), 0.5f);
-        } else if (tex.decal_mode == RT_DECAL_REPLACE_KS) {
-            uv_of(S, s, p, u, v);
-            tex_sample(S, tex, u, v, p, ks, c);
-        } else if (tex.decal_mode == RT_DECAL_REPLACE_ALL) {
-            uv_of(S, s, p, u, v);
-            replace_color = mk(0, 0, 0);
-            tex_sample(S, tex, u, v, p, replace_color, c);
-            replace_all = true;
-            return;
-        }
-    }
-}
-
-// ---- lights (Light::get_sample, src/lights.cpp) ------------------------------------------------------
-__device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal, float ru, float rv, V &radiance, V &ldir,
-                             float &dist, Counters &c) {
-    const float pi = 3.14159265359f;
-    radiance = mk(0, 0, 0);
-    switch (L.type) {
-        case RT_LIGHT_POINT: {
-            V du = sub(mk(L.position), p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            if (d2 < 1e-6f) {
-                ldir = du;
-                return;
-            }
-            ldir = scl(du, rt_div(1.0f, dist));
-            radiance = scl(mk(L.color), rt_div(1.0f, d2));
-            return;
-        }
-        case RT_LIGHT_AREA: {
-            float uo = (ru - 0.5f) * L.size, vo = (rv - 0.5f) * L.size;
-            V sp = add(add(mk(L.position), scl(mk(L.u), uo)), scl(mk(L.v), vo));
-            V du = sub(sp, p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            ldir = scl(du, rt_div(1.0f, dist));
-            float cos_l = dot(mk(L.normal), scl(ldir, -1.0f));
-            if (cos_l <= 0.0f) return;
-            float area = L.size * L.size;
-            radiance = scl(mk(L.color), rt_div(area * cos_l, d2));
-            return;
-        }
-        case RT_LIGHT_DIRECTIONAL: {
-            dist = 3.402823466e+38f;
-            ldir = scl(mk(L.direction), -1.0f);
-            radiance = mk(L.color);
-            return;
-        }
-        case RT_LIGHT_SPOT: {
-            V du = sub(mk(L.position), p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            if (d2 < 1e-6f) {
-                ldir = du;
-                return;
-            }
-            ldir = scl(du, rt_div(1.0f, dist));
-            float cos_alpha = dot(scl(ldir, -1.0f), mk(L.direction));
-            float spot = 0.0f;
-            if (cos_alpha > L.cos_falloff) {
-                spot = 1.0f;
-            } else if (cos_alpha > L.cos_coverage) {
-                float ratio = rt_div(cos_alpha - L.cos_coverage, L.cos_falloff - L.cos_coverage);
-                spot = ratio * ratio * ratio * ratio;
-            }
-            radiance = scl(mk(L.color), rt_div(spot, d2));
-            return;
-        }
-        case RT_LIGHT_ENV: {
-            dist = 3.402823466e+38f;
-            float phi = 2.0f * pi * ru, cos_t, sin_t, pdf;
-            if (L.cosine_sampling) {
-                cos_t = rt_sqrt(rv);
-                sin_t = rt_sqrt(1.0f - cos_t * cos_t);
-                pdf = rt_div(cos_t, pi);
-            } else {
-                cos_t = rv;
-                sin_t = rt_sqrt(1.0f - cos_t * cos_t);
-                pdf = 1.0f / (2.0f * pi);
-            }
-            float lx = sin_t * rt_cos(phi), ly = sin_t * rt_sin(phi), lz = cos_t;
-            V w = normal;
-            V up = absf(w.y) < 0.9f ? mk(0, 1, 0) : mk(0, 0, 1);
-            V u = normalize(cross(up, w));
-            V vb = normalize(cross(w, u));
-            ldir = normalize(add(add(scl(u, lx), scl(vb, ly)), scl(w, lz)));
-            float uu, vv;
-            if (L.is_probe)
-                probe_uv(ldir, uu, vv);
-            else
-                latlong_uv(ldir, uu, vv);
-            if (L.image >= 0) image_sample(S, S.images[L.image], true, uu, vv, radiance, c);
-            if (pdf < 1e-6f) pdf = 1e-6f;
-            radiance = scl(radiance, rt_div(1.0f, pdf));
-            return;
-        }
-        case RT_LIGHT_TRIANGLE: {
-            float sr = rt_sqrt(ru);
-            float u = 1.0f - sr, v = rv * sr, w = 1.0f - u - v;
-            V sp = add(add(scl(mk(L.v0), w), scl(mk(L.v1), u)), scl(mk(L.v2), v));
-            V du = sub(sp, p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            ldir = scl(du, rt_div(1.0f, dist));
-            float cos_l = absf(dot(mk(L.normal), scl(ldir, -1.0f)));
-            radiance = scl(mk(L.color), rt_div(L.area * cos_l, d2));
-            return;
-        }
-        case RT_LIGHT_SPHERE: {
-            const rt_sphere &s = S.spheres[L.sphere];
-            float phi = 2.0f * 3.14159265359f * ru;
-            float cos_t = 1.0f - 2.0f * rv;
-            float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
-            V unit = mk(sin_t * rt_cos(phi), sin_t * rt_sin(phi), cos_t);
-            // the reference transforms the scalar copies of the sampled point, which are still zero
-            // (src/lights.cpp:418-422): the position used is model * (0,0,0,1)
-            V sp = xpoint(s.model, mk(0, 0, 0));
-            V nl = normalize(xdir(s.normal, unit));
-            V du = sub(sp, p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            ldir = scl(du, rt_div(1.0f, dist));
-            float cos_l = dot(nl, scl(ldir, -1.0f));
-            if (cos_l <= 0.0f) return;
-            radiance = scl(mk(L.color), rt_div(L.area * cos_l, d2));
-            return;
-        }
-    }
-    ldir = mk(0, 0, 0);
-    dist = 0.f;
-}
-
-// calculate_color, src/ray_trace.cpp:154-406 (the last-blocker cache :158-159,207-226 is not used).
-template <bool COUNT>
-__device__ V calculate_color(const DevScene &S, V normal, const rt_material &m, const Surface &s, V p, V ray_origin, float time,
-                             bool is_hdr, bool include_ambient, uint32_t key, Counters &c) {
-    V kd, ks, kd_rr, rep;
-    bool replace_all;
-    resolve_textures(S, s, p, m, kd, ks, kd_rr, replace_all, rep, c);
-    if (replace_all) return rep;
-    V color = mk(0, 0, 0);
-    if (include_ambient) color = add(color, mul(mk(m.ambient), mk(S.ambient)));
-    const V view = normalize(sub(ray_origin, p));
-    const float seps = S.seps;
-    uint32_t k = 0;
-    for (int li = 0; li < S.n_lights; ++li) {
-        const rt_light &L = S.lights[li];
-        const int ns = L.samples;
-        const float weight = rt_div(1.0f, (float)ns);
-        for (int si = 0; si < ns; ++si, ++k) {
-            float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
-            V rad, ldir;
-            float dist;
-            light_sample(S, L, p, normal, r1, r2, rad, ldir, dist, c);
-            if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
-            V so = add(p, scl(ldir, seps));
-            ++c.shadow;
-            Hit sh = traverse<true, COUNT>(S, so, ldir, time, false, seps, dist, c);
-            if (sh.prim != -1 && sh.t < dist - seps) continue;
-            float ndotl = max_std(dot(normal, ldir), 0.0f);
-            V hv = normalize(add(ldir, view));
-            V fd = mk(0, 0, 0), fs = mk(0, 0, 0);
-            const float p_exp = m.phong_exponent;
-            const float PI = 3.14159265359f;
-            switch (m.brdf) {
-                case RT_BRDF_ORIGINAL_BLINN_PHONG: {
-                    fd = scl(kd, ndotl);
-                    float ndoth = max_std(dot(normal, hv), 0.0f);
-                    fs = scl(ks, rt_pow(ndoth, p_exp));
-                    break;
-                }
-                case RT_BRDF_ORIGINAL_PHONG: {
-                    fd = scl(kd, ndotl);
-                    V R = reflect_dir(normal, scl(ldir, -1.0f), 0.f, 0);
-                    float rdoth = max_std(dot(R, view), 0.0f);
-                    fs = scl(ks, rt_pow(rdoth, p_exp));
-                    break;
-                }
-                case RT_BRDF_MODIFIED_BLINN_PHONG: {
-                    float ndoth = max_std(dot(normal, hv), 0.0f);
-                    if (m.normalized) {
-                        fd = scl(kd, 1.0f / PI * ndotl);
-                        float norm = rt_div(p_exp + 8.0f, 8.0f * PI);
-                        fs = scl(ks, norm * rt_pow(ndoth, p_exp) * ndotl);
-                    } else {
-                        fd = scl(kd, ndotl);
-                        fs = scl(ks, rt_pow(ndoth, p_exp) * ndotl);
-                    }
-                    break;
-                }
-                case RT_BRDF_MODIFIED_PHONG: {
-                    V R = reflect_dir(normal, scl(ldir, -1.0f), 0.f, 0);
-                    float rdoth = max_std(dot(R, view), 0.0f);
-                    if (m.normalized) {
-                        fd = scl(kd, 1.0f / PI * ndotl);
-                        float norm = rt_div(p_exp + 2.0f, 2.0f * PI);
-                        fs = scl(ks, norm * rt_pow(rdoth, p_exp) * ndotl);
-                    } else {
-                        fd = scl(kd, ndotl);
-                        fs = scl(ks, rt_pow(rdoth, p_exp) * ndotl);
-                    }
-                    break;
-                }
-                case RT_BRDF_TORRANCE_SPARROW: {
-                    float ndoth = max_std(dot(normal, hv), 0.0f);
-                    float ndotv = max_std(dot(normal, view), 0.0f);
-                    float vdoth = max_std(dot(view, hv), 0.0f);
-                    float D = rt_div(p_exp + 2.0f, 2.0f * PI) * rt_pow(ndoth, p_exp);
-                    float f_term = rt_pow(1.0f - vdoth, 5.0f);
-                    V one = mk(1, 1, 1);
-                    V F = add(ks, scl(sub(one, ks), f_term));
-                    float G = 1.0f;
-                    if (vdoth > 1e-6f) {
-                        float g1 = rt_div(2.0f * ndoth * ndotv, vdoth);
-                        float g2 = rt_div(2.0f * ndoth * ndotl, vdoth);
-                        G = min_std(1.0f, min_std(g1, g2));
-                    }
-                    if (ndotv > 1e-6f) {
-                        float denom = 4.0f * ndotv;
-                        fs = scl(F, rt_div(D * G, denom));
-                    }
-                    if (m.kdfresnel)
-                        fd = mul(scl(kd, ndotl), sub(one, F));
-                    else
-                        fd = scl(kd, 1.0f / PI * ndotl);
-                    break;
-                }
-            }
-            fd = scl(mul(fd, rad), weight);
-            fs = scl(mul(fs, rad), weight);
-            color = add(color, fd);
-            color = add(color, fs);
-        }
-    }
-    if (!is_hdr) color = scl(color, 0.004f);
-    return color;
-}
-
-// ---- camera (camera::get_samples, src/camera.cpp:117-224) --------------------------------------------
-__device__ void camera_sample(const rt_camera_desc &cam, int i, int j, int s, int grid_n, uint32_t key, V &o, V &dir, float &time) {
-    V pos = mk(cam.position), cu = mk(cam.u), cv = mk(cam.v), cw = mk(cam.w), center = mk(cam.center);
-    if (cam.num_samples == 1) {
-        float su = cam.near_left + rt_div((cam.near_right - cam.near_left) * (i + 0.5f), (float)cam.resx);
-        float sv = cam.near_bottom + rt_div((cam.near_top - cam.near_bottom) * (j + 0.5f), (float)cam.resy);
-        V target = add(add(center, scl(cu, su)), scl(cv, sv));
-        dir = normalize(sub(target, pos));
-        o = pos;
-        time = rnd(key, DIM_CAM_TIME);
-        return;
-    }
-    int sy = s / grid_n, sx = s % grid_n;
-    float r1 = rnd(key, DIM_CAM_R1), r2 = rnd(key, DIM_CAM_R2);
-    float sub_u = rt_div(sx + r1, (float)grid_n);
-    float sub_v = rt_div(sy + r2, (float)grid_n);
-    float su = cam.near_left + rt_div((cam.near_right - cam.near_left) * (i + sub_u), (float)cam.resx);
-    float sv = cam.near_bottom + rt_div((cam.near_top - cam.near_bottom) * (j + sub_v), (float)cam.resy);
-    V target = add(add(center, scl(cu, su)), scl(cv, sv));
-    dir = normalize(sub(target, pos));
-    o = pos;
-    if (cam.aperture_size > 0.0f && cam.focus_distance > 0.0f) {
-        float cos_theta = -dot(dir, cw);
-        if (absf(cos_theta) < 1e-6f) cos_theta = 1e-6f;
-        float t = rt_div(cam.focus_distance, cos_theta);
-        V focal = add(pos, scl(dir, t));
-        float r3 = rnd(key, DIM_CAM_R3), r4 = rnd(key, DIM_CAM_R4);
-        float lens_x = (r3 - 0.5f) * cam.aperture_size;
-        float lens_y = (r4 - 0.5f) * cam.aperture_size;
-        V lens = add(scl(cu, lens_x), scl(cv, lens_y));
-        o = add(pos, lens);
-        dir = normalize(sub(focal, o));
-    }
-    time = rnd(key, DIM_CAM_TIME);
-}
-
-// ---- pending rays of one camera sample -----------------------------------------------------------------
-struct PathItem {
-    V o, d, thr;
-    uint32_t key;
-    int depth_flags;   // depth | culling << 16 | diffuse bounce << 17
-};
-
-struct LaunchParams {
-    int tiles_x, tiles_y;   // image size in 32x32 tiles
-    int rank, world;        // tile ownership: tile k belongs to rank k % world
-    int n_owned;            // tiles of this rank
-    int grid_n;             // floor(sqrt(num_samples))
-    int n_samples;          // grid_n^2 (or 1)
-};
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -976,68 +123,155 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// One lane = one pixel.  process_pixel (src/main.cpp:451-484) + ray_tracer::trace (src/ray_trace.cpp:1141-1172)
-// with trace_rec (:646-869) / path_trace (:871-1139) flattened into a depth-first walk over PathItems.
-template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
-    render_kernel(DevScene S, rt_camera_desc cam, LaunchParams lp, float *__restrict__ out, unsigned long long *__restrict__ stats) {
-    // workgroup -> (owned tile, 16x16 quadrant); wave -> 8x8 sub-tile; lane -> pixel
-    const int owned = blockIdx.x >> 2, quad = blockIdx.x & 3;
-    const int tile = owned * lp.world + lp.rank;
-    const int tx = tile % lp.tiles_x, ty = tile / lp.tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = tx * TILE + (quad & 1) * BLOCK_EDGE + (wave & 1) * 8 + (lane & 7);
-    const int j = ty * TILE + (quad >> 1) * BLOCK_EDGE + (wave >> 1) * 8 + (lane >> 3);
+__device__ __forceinline__ void accum_add(float *accum, int slot, V v) {
+    unsafeAtomicAdd(accum + 3 * (size_t)slot + 0, v.x);
+    unsafeAtomicAdd(accum + 3 * (size_t)slot + 1, v.y);
+    unsafeAtomicAdd(accum + 3 * (size_t)slot + 2, v.z);
+}
+
+__device__ __forceinline__ void flush_counters(const Counters &c, unsigned long long *stats, bool detailed) {
+    uint32_t vals[9] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (!detailed && (k >= 3 && k <= 6)) continue;
+        uint32_t v = wave_sum(vals[k]);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(stats + k, (unsigned long long)v);
+    }
+}
+
+// ---- generate: camera::get_samples (src/camera.cpp:117-224) for every (pixel, sample) of the batch ----------
+__global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch b, Wavefront W, unsigned long long *__restrict__ stats) {
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned total = (unsigned)b.n_pixels * (unsigned)b.n_samples;
     Counters c;
     memset(&c, 0, sizeof c);
-    if (i < cam.resx && j < cam.resy) {
-        const float pixelv = 1.0f - rt_div((float)j, (float)(cam.resy - 1));
-        const float pixelu = rt_div((float)i, (float)(cam.resx - 1));
+    bool valid = false;
+    int i = 0, j = 0, s = 0;
+    if (g < total) {
+        s = (int)(g / (unsigned)b.n_pixels);
+        batch_pixel(b, (int)(g % (unsigned)b.n_pixels), i, j);
+        valid = i < cam.resx && j < cam.resy;
+        W.accum[3 * (size_t)g] = 0.f;
+        W.accum[3 * (size_t)g + 1] = 0.f;
+        W.accum[3 * (size_t)g + 2] = 0.f;
+    }
+    const unsigned idx = wave_append(valid, W.path_count);
+    if (valid) {
         const uint32_t pixel_index = (uint32_t)j * (uint32_t)cam.resx + (uint32_t)i;
-        const bool is_hdr = cam.is_hdr != 0;
-        const bool pt = cam.path_tracing != 0;
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-        PathItem stack[PATH_STACK];
-        for (int s = 0; s < lp.n_samples; ++s) {
-            const uint32_t skey = sample_key(cam.seed, pixel_index, (uint32_t)s);
-            float time;
-            {
-                V o, d;
-                camera_sample(cam, i, j, s, lp.grid_n, skey, o, d, time);
-                stack[0].o = o;
-                stack[0].d = d;
-                stack[0].thr = mk(1.f, 1.f, 1.f);
-                stack[0].key = child_key(skey, BRANCH_ROOT);
-                stack[0].depth_flags = 0;
+        const uint32_t skey = sample_key(cam.seed, pixel_index, (uint32_t)s);
+        V o, d;
+        float time;
+        camera_sample(cam, i, j, s, b.grid_n, skey, o, d, time);
+        ++c.primary;
+        const PathQueue &Q = W.q[0];
+        Q.o_time[idx] = make_float4(o.x, o.y, o.z, time);
+        Q.d_key[idx] = make_float4(d.x, d.y, d.z, __uint_as_float(child_key(skey, BRANCH_ROOT)));
+        Q.thr_slot[idx] = make_float4(1.f, 1.f, 1.f, __uint_as_float(g));
+        Q.depth_flags[idx] = 0;
+    }
+    flush_counters(c, stats, false);
+}
+
+// ---- closest: bvh::intersect (src/bvh.cpp:383-480) for every path of generation `gen` -------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
+    unsigned count = W.path_count[gen];
+    if (count > W.capacity) count = W.capacity;
+    const PathQueue &Q = W.q[gen & 1];
+    Counters c;
+    memset(&c, 0, sizeof c);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < count; idx += gridDim.x * 256u) {
+        const float4 ot = Q.o_time[idx], dk = Q.d_key[idx];
+        const int df = Q.depth_flags[idx];
+        if (whitted && (float)(df & 0xffff) >= S.max_depth) {   // depth limit: no traversal, background (src/ray_trace.cpp:649-679)
+            W.hit_prim[idx] = -3;
+            continue;
+        }
+        const Hit h = traverse<false, COUNT>(S, mk(ot.x, ot.y, ot.z), mk(dk.x, dk.y, dk.z), ot.w, ((df >> 16) & 1) != 0, S.ieps, 1e30f, c);
+        W.hit_t[idx] = h.t;
+        W.hit_prim[idx] = h.prim;
+    }
+    flush_counters(c, stats, COUNT);
+}
+
+__device__ __forceinline__ void put_path(const Wavefront &W, int gen, unsigned idx, V o, V d, float time, V thr, uint32_t key, int slot,
+                                         int depth_flags) {
+    if (idx >= W.capacity) {
+        *W.overflow = 1u;
+        return;
+    }
+    const PathQueue &Q = W.q[gen & 1];
+    Q.o_time[idx] = make_float4(o.x, o.y, o.z, time);
+    Q.d_key[idx] = make_float4(d.x, d.y, d.z, __uint_as_float(key));
+    Q.thr_slot[idx] = make_float4(thr.x, thr.y, thr.z, __int_as_float(slot));
+    Q.depth_flags[idx] = depth_flags;
+}
+
+// ---- shade: the hit-side half of trace_rec (src/ray_trace.cpp:646-869) / path_trace (:871-1139) ------------------
+// Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
+template <bool PT>
+__global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
+    unsigned count = W.path_count[gen];
+    if (count > W.capacity) count = W.capacity;
+    const PathQueue &Q = W.q[gen & 1];
+    unsigned *next_count = W.path_count + gen + 1;
+    unsigned *vcount = W.vertex_count + gen;
+    const bool is_hdr = cam.is_hdr != 0;
+    Counters c;
+    memset(&c, 0, sizeof c);
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < count; base += stride) {
+        const unsigned idx = base + (threadIdx.x & 63u);
+        const bool active = idx < count;
+        // per-lane outputs of this pass
+        bool want_vertex = false;
+        V v_p = mk(0, 0, 0), v_n = mk(0, 0, 0), v_view = mk(0, 0, 0), v_kd = mk(0, 0, 0), v_ks = mk(0, 0, 0), v_w = mk(0, 0, 0);
+        int v_mat = 0;
+        int n_children = 0;          // explicit children 0 (reflect) and 1 (refract), or `n_children` diffuse bounces
+        bool diffuse = false;
+        V c_o[2], c_d[2], c_thr[2];
+        uint32_t c_key[2];
+        int c_df[2];
+        V b_origin = mk(0, 0, 0), b_normal = mk(0, 0, 0), b_kd = mk(0, 0, 0), b_thr = mk(0, 0, 0);
+        float b_helper_x = 0.f, b_rr = 1.f;
+        uint32_t key = 0;
+        int slot = 0, depth = 0;
+        bool culling = false;
+        float time = 0.f;
+        if (active) {
+            const float4 ot = Q.o_time[idx], dk = Q.d_key[idx], ts = Q.thr_slot[idx];
+            const int df = Q.depth_flags[idx];
+            const V o = mk(ot.x, ot.y, ot.z), d = mk(dk.x, dk.y, dk.z), thr = mk(ts.x, ts.y, ts.z);
+            time = ot.w;
+            key = __float_as_uint(dk.w);
+            slot = __float_as_int(ts.w);
+            depth = df & 0xffff;
+            culling = ((df >> 16) & 1) != 0;
+            const bool diffuse_bounce = ((df >> 17) & 1) != 0;
+            Hit h;
+            h.prim = W.hit_prim[idx];
+            h.t = h.prim == -3 ? 0.f : W.hit_t[idx];
+            float pixelu = 0.f, pixelv = 0.f;
+            if (!PT && (h.prim == -1 || h.prim == -3) && !is_hdr && S.bg_tex >= 0) {
+                // LDR background images are looked up by pixel position (src/main.cpp:455-456); slots are laid out
+                // sample-major over the batch's pixel-local indices
+                int pi, pj;
+                batch_pixel(b, slot % b.n_pixels, pi, pj);
+                pixelv = 1.0f - rt_div((float)pj, (float)(cam.resy - 1));
+                pixelu = rt_div((float)pi, (float)(cam.resx - 1));
             }
-            ++c.primary;
-            int top = 0;
-            V sample = mk(0, 0, 0);
-            while (top >= 0) {
-                const PathItem it = stack[top--];
-                const int depth = it.depth_flags & 0xffff;
-                const bool culling = ((it.depth_flags >> 16) & 1) != 0;
-                const bool diffuse_bounce = ((it.depth_flags >> 17) & 1) != 0;
-                const V o = it.o, d = it.d, thr = it.thr;
-                const uint32_t key = it.key;
-                if (!pt && (float)depth >= S.max_depth) {   // Whitted depth limit returns the background (:649-679)
-                    sample = add(sample, mul(thr, background(S, cam, d, true, pixelu, pixelv, c)));
-                    continue;
+            if (h.prim == -1 || h.prim == -3) {
+                V bgc;
+                if (PT && diffuse_bounce && S.bg_tex >= 0 && S.textures[S.bg_tex].image >= 0) {
+                    // a diffuse-bounce miss under an environment map fetches one fixed texel (the reference reads
+                    // zeroed scalar copies of the sampled direction, src/ray_trace.cpp:10-12,1093-1116)
+                    bgc = mk(0, 0, 0);
+                    tex_sample(S, S.textures[S.bg_tex], S.is_probe ? 0.5f : 1.0f, 0.5f, mk(0, 0, 0), bgc, c);
+                } else {
+                    bgc = background(S, cam, d, !PT, pixelu, pixelv, c);
                 }
-                const Hit h = traverse<false, COUNT>(S, o, d, time, culling, S.ieps, 1e30f, c);
-                if (h.prim == -1) {
-                    // A diffuse-bounce miss under an environment map always fetches one fixed texel: the reference
-                    // reads scalar copies of the sampled direction that are still zero (src/ray_trace.cpp:10-12,1093-1116),
-                    // which maps to (u, v) = (1, 1/2) lat-long or (1/2, 1/2) probe.
-                    if (diffuse_bounce && S.bg_tex >= 0 && S.textures[S.bg_tex].image >= 0) {
-                        V bgc = mk(0, 0, 0);
-                        tex_sample(S, S.textures[S.bg_tex], S.is_probe ? 0.5f : 1.0f, 0.5f, mk(0, 0, 0), bgc, c);
-                        sample = add(sample, mul(thr, bgc));
-                    } else {
-                        sample = add(sample, mul(thr, background(S, cam, d, !pt, pixelu, pixelv, c)));
-                    }
-                    continue;
-                }
+                accum_add(W.accum, slot, mul(thr, bgc));
+            } else {
                 ++c.shaded;
                 const Surface sf = surface_of(S, h);
                 const rt_material &m = S.materials[sf.material];
@@ -1047,8 +281,10 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                 apply_normal_map(S, sf, p, normal, c);
                 apply_bump_map(S, sf, p, normal, c);
                 const float seps = S.seps;
-                if (!pt) {
-                    // ---- trace_rec -----------------------------------------------------------------
+                const int child_df = (depth + 1) | ((int)culling << 16);
+                if (!PT) {
+                    // ---- trace_rec ---------------------------------------------------------------------
+                    V shade_p = p, shade_n = normal;
                     if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
                         V R = reflect_dir(normal, d, m.roughness, key);
                         V coef = mk(m.mirror);
@@ -1056,16 +292,14 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                             float Fs = conductor_fresnel(absf(dot(d, normal)), m.refraction_index, m.absorption_index);
                             coef = mul(mk(Fs, Fs, Fs), mk(m.mirror));
                         }
-                        p = add(p, scl(normal, seps));
-                        V own = calculate_color<COUNT>(S, normal, m, sf, p, o, time, is_hdr, true, key, c);
-                        sample = add(sample, mul(thr, own));
-                        ++c.secondary;
-                        PathItem &n = stack[++top];
-                        n.o = p;
-                        n.d = R;
-                        n.thr = mul(thr, coef);
-                        n.key = child_key(key, BRANCH_REFLECT);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16);
+                        p = add(p, scl(normal, seps));   // the reference offsets the hit point in place (:736-743)
+                        shade_p = p;
+                        n_children = 1;
+                        c_o[0] = p;
+                        c_d[0] = R;
+                        c_thr[0] = mul(thr, coef);
+                        c_key[0] = child_key(key, BRANCH_REFLECT);
+                        c_df[0] = child_df;
                     } else if (m.type == RT_MAT_DIELECTRIC) {
                         float n1 = 1.0f, n2 = m.refraction_index;
                         float cos_theta = dot(d, normal);
@@ -1077,177 +311,294 @@ __global__ void __launch_bounds__(BLOCK_EDGE *BLOCK_EDGE)
                             normal = scl(normal, -1.0f);
                             cos_theta = -cos_theta;
                         }
+                        shade_n = normal;
                         float cos_i = -cos_theta;
                         cos_i = cos_i < 0.0f ? 0.0f : (cos_i > 1.0f ? 1.0f : cos_i);
                         float r0 = rt_div(n1 - n2, n1 + n2);
                         r0 = r0 * r0;
                         const float F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_i, 5.0f);
-                        V rdir = reflect_dir(normal, d, m.roughness, key);
+                        n_children = 1;
+                        c_o[0] = add(p, scl(normal, seps));
+                        c_d[0] = reflect_dir(normal, d, m.roughness, key);
+                        c_thr[0] = scl(mul(thr, mk(m.mirror)), F);
+                        c_key[0] = child_key(key, BRANCH_REFLECT);
+                        c_df[0] = child_df;
                         V tdir;
-                        const bool refracts = refract_dir(normal, d, n1, n2, m.roughness, key, tdir);
-                        V own = calculate_color<COUNT>(S, normal, m, sf, p, o, time, is_hdr, true, key, c);
-                        sample = add(sample, mul(thr, own));
-                        if (refracts) {   // pushed first so that the reflected child is walked first, as in the reference
+                        if (refract_dir(normal, d, n1, n2, m.roughness, key, tdir)) {
                             V att = mk(1.f, 1.f, 1.f);
                             if (!entering) {
                                 V a = scl(mk(m.absorption_coefficient), -h.t);
                                 att = mk(rt_exp(a.x), rt_exp(a.y), rt_exp(a.z));
                             }
-                            ++c.secondary;
-                            PathItem &n = stack[++top];
-                            n.o = add(p, scl(normal, -seps));
-                            n.d = tdir;
-                            n.thr = scl(mul(thr, att), 1.0f - F);
-                            n.key = child_key(key, BRANCH_REFRACT);
-                            n.depth_flags = (depth + 1);   // refracted rays never cull (:845)
+                            n_children = 2;
+                            c_o[1] = add(p, scl(normal, -seps));
+                            c_d[1] = tdir;
+                            c_thr[1] = scl(mul(thr, att), 1.0f - F);
+                            c_key[1] = child_key(key, BRANCH_REFRACT);
+                            c_df[1] = depth + 1;   // refracted rays never cull (:845)
                         }
-                        ++c.secondary;
-                        PathItem &n = stack[++top];
-                        n.o = add(p, scl(normal, seps));
-                        n.d = rdir;
-                        n.thr = scl(mul(thr, mk(m.mirror)), F);
-                        n.key = child_key(key, BRANCH_REFLECT);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16);
+                    }
+                    // own colour: calculate_color(include_ambient = true) at (shade_p, shade_n)
+                    V kd, ks, kd_rr, rep;
+                    bool replace_all;
+                    resolve_textures(S, sf, shade_p, m, kd, ks, kd_rr, replace_all, rep, c);
+                    if (replace_all) {
+                        accum_add(W.accum, slot, mul(thr, rep));
                     } else {
-                        V own = calculate_color<COUNT>(S, normal, m, sf, p, o, time, is_hdr, true, key, c);
-                        sample = add(sample, mul(thr, own));
-                    }
-                    continue;
-                }
-                // ---- path_trace ---------------------------------------------------------------------
-                V kd, ks, kd_rr, rep;
-                bool replace_all;
-                resolve_textures(S, sf, p, m, kd, ks, kd_rr, replace_all, rep, c);
-                if (replace_all) {
-                    sample = add(sample, mul(thr, rep));
-                    continue;
-                }
-                V emission = sf.kind == 0 ? mk(S.instances[sf.instance].emission) : (sf.kind == 1 ? mk(S.spheres[sf.index].emission) : mk(0, 0, 0));
-                if (m.type != RT_MAT_REGULAR) {
-                    if (!((float)depth < S.max_depth)) {
-                        sample = add(sample, mul(thr, emission));   // specular surface at the depth limit keeps only its emission
-                        continue;
-                    }
-                    if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
-                        V R = reflect_dir(normal, d, m.roughness, key);
-                        V coef = mk(m.mirror);
-                        if (m.type == RT_MAT_CONDUCTOR) {
-                            float Fs = conductor_fresnel(absf(dot(d, normal)), m.refraction_index, m.absorption_index);
-                            coef = mul(mk(Fs, Fs, Fs), mk(m.mirror));
+                        const float scale = is_hdr ? 1.0f : 0.004f;
+                        accum_add(W.accum, slot, mul(thr, scl(mul(mk(m.ambient), mk(S.ambient)), scale)));
+                        if (S.n_lights > 0) {
+                            want_vertex = true;
+                            v_p = shade_p;
+                            v_n = shade_n;
+                            v_view = normalize(sub(o, shade_p));
+                            v_kd = kd;
+                            v_ks = ks;
+                            v_w = scl(thr, scale);
+                            v_mat = sf.material;
                         }
-                        ++c.secondary;
-                        PathItem &n = stack[++top];
-                        n.o = add(p, scl(normal, seps));
-                        n.d = R;
-                        n.thr = mul(thr, coef);
-                        n.key = child_key(key, BRANCH_REFLECT);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16);
+                    }
+                } else {
+                    // ---- path_trace ------------------------------------------------------------------------
+                    V kd, ks, kd_rr, rep;
+                    bool replace_all;
+                    const uint32_t texels_before = c.texels;
+                    resolve_textures(S, sf, p, m, kd, ks, kd_rr, replace_all, rep, c);
+                    const uint32_t texels_resolve = c.texels - texels_before;
+                    if (replace_all) {
+                        accum_add(W.accum, slot, mul(thr, rep));
                     } else {
-                        float n1 = 1.0f, n2 = m.refraction_index;
-                        float cos_theta = dot(d, normal);
-                        const bool entering = cos_theta < 0.0f;
-                        V rn = normal;
-                        if (!entering) {
-                            float tmp = n1;
-                            n1 = n2;
-                            n2 = tmp;
-                            rn = scl(normal, -1.0f);
+                        V emission = sf.kind == 0 ? mk(S.instances[sf.instance].emission)
+                                                  : (sf.kind == 1 ? mk(S.spheres[sf.index].emission) : mk(0, 0, 0));
+                        if (m.type != RT_MAT_REGULAR) {
+                            if (!((float)depth < S.max_depth)) {
+                                accum_add(W.accum, slot, mul(thr, emission));   // specular surface at the depth limit keeps its emission only
+                            } else if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
+                                V coef = mk(m.mirror);
+                                if (m.type == RT_MAT_CONDUCTOR) {
+                                    float Fs = conductor_fresnel(absf(dot(d, normal)), m.refraction_index, m.absorption_index);
+                                    coef = mul(mk(Fs, Fs, Fs), mk(m.mirror));
+                                }
+                                n_children = 1;
+                                c_o[0] = add(p, scl(normal, seps));
+                                c_d[0] = reflect_dir(normal, d, m.roughness, key);
+                                c_thr[0] = mul(thr, coef);
+                                c_key[0] = child_key(key, BRANCH_REFLECT);
+                                c_df[0] = child_df;
+                            } else {
+                                float n1 = 1.0f, n2 = m.refraction_index;
+                                float cos_theta = dot(d, normal);
+                                const bool entering = cos_theta < 0.0f;
+                                V rn = normal;
+                                if (!entering) {
+                                    float tmp = n1;
+                                    n1 = n2;
+                                    n2 = tmp;
+                                    rn = scl(normal, -1.0f);
+                                } else {
+                                    cos_theta = -cos_theta;
+                                }
+                                float r0 = rt_div(n1 - n2, n1 + n2);
+                                r0 = r0 * r0;
+                                const float F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_theta, 5.0f);
+                                V T;
+                                const bool refracts = refract_dir(rn, d, n1, n2, m.roughness, key, T);
+                                n_children = 1;
+                                c_o[0] = add(p, scl(rn, seps));
+                                c_d[0] = reflect_dir(rn, d, m.roughness, key);
+                                c_thr[0] = refracts ? scl(mul(thr, mk(m.mirror)), F) : mul(thr, mk(m.mirror));
+                                c_key[0] = child_key(key, BRANCH_REFLECT);
+                                c_df[0] = child_df;
+                                if (refracts) {
+                                    V att = mk(1.f, 1.f, 1.f);
+                                    if (!entering) {
+                                        V a = scl(mk(m.absorption_coefficient), -h.t);
+                                        att = mk(rt_exp(a.x), rt_exp(a.y), rt_exp(a.z));
+                                    }
+                                    n_children = 2;
+                                    c_o[1] = add(p, scl(rn, -seps));
+                                    c_d[1] = T;
+                                    c_thr[1] = scl(mul(thr, att), 1.0f - F);
+                                    c_key[1] = child_key(key, BRANCH_REFRACT);
+                                    c_df[1] = child_df;
+                                }
+                            }
                         } else {
-                            cos_theta = -cos_theta;
-                        }
-                        float r0 = rt_div(n1 - n2, n1 + n2);
-                        r0 = r0 * r0;
-                        const float F = r0 + (1.0f - r0) * rt_pow(1.0f - cos_theta, 5.0f);
-                        V R = reflect_dir(rn, d, m.roughness, key);
-                        V T;
-                        const bool refracts = refract_dir(rn, d, n1, n2, m.roughness, key, T);
-                        if (refracts) {
-                            V att = mk(1.f, 1.f, 1.f);
-                            if (!entering) {
-                                V a = scl(mk(m.absorption_coefficient), -h.t);
-                                att = mk(rt_exp(a.x), rt_exp(a.y), rt_exp(a.z));
+                            accum_add(W.accum, slot, mul(thr, emission));
+                            float rr_prob = 1.0f;
+                            bool alive = true;
+                            if (cam.russian_roulette && depth >= cam.min_recursion_depth) {
+                                float max_refl = max_std(max_std(kd_rr.x, kd_rr.y), kd_rr.z);
+                                rr_prob = min_std(max_refl, 0.99f);
+                                if (rnd(key, DIM_RR) > rr_prob) alive = false;
                             }
-                            ++c.secondary;
-                            PathItem &n = stack[++top];
-                            n.o = add(p, scl(rn, -seps));
-                            n.d = T;
-                            n.thr = scl(mul(thr, att), 1.0f - F);
-                            n.key = child_key(key, BRANCH_REFRACT);
-                            n.depth_flags = (depth + 1) | ((int)culling << 16);
+                            if (alive) {
+                                if (cam.next_event_estimation) {
+                                    c.texels += texels_resolve;   // the reference resolves the textures again inside calculate_color
+                                    if (S.n_lights > 0) {
+                                        want_vertex = true;
+                                        v_p = p;
+                                        v_n = normal;
+                                        v_view = normalize(sub(o, p));
+                                        v_kd = kd;
+                                        v_ks = ks;
+                                        v_w = scl(thr, 0.004f);   // path_trace calls calculate_color with is_hdr = false (:1083)
+                                        v_mat = sf.material;
+                                    }
+                                }
+                                if ((float)depth < S.max_depth) {
+                                    diffuse = true;
+                                    n_children = (depth == 0 && cam.splitting_factor > 1) ? cam.splitting_factor : 1;
+                                    b_origin = add(p, scl(normal, seps));
+                                    b_normal = normal;
+                                    b_helper_x = helper_x;
+                                    b_kd = kd;
+                                    b_thr = thr;
+                                    b_rr = rr_prob;
+                                }
+                            }
                         }
-                        ++c.secondary;
-                        PathItem &n = stack[++top];
-                        n.o = add(p, scl(rn, seps));
-                        n.d = R;
-                        n.thr = refracts ? scl(mul(thr, mk(m.mirror)), F) : mul(thr, mk(m.mirror));
-                        n.key = child_key(key, BRANCH_REFLECT);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16);
-                    }
-                    continue;
-                }
-                sample = add(sample, mul(thr, emission));
-                float rr_prob = 1.0f;
-                if (cam.russian_roulette && depth >= cam.min_recursion_depth) {
-                    float max_refl = max_std(max_std(kd_rr.x, kd_rr.y), kd_rr.z);
-                    rr_prob = min_std(max_refl, 0.99f);
-                    if (rnd(key, DIM_RR) > rr_prob) continue;
-                }
-                if (cam.next_event_estimation) {
-                    V direct = calculate_color<COUNT>(S, normal, m, sf, p, o, time, false, false, key, c);
-                    sample = add(sample, mul(thr, direct));
-                }
-                if ((float)depth < S.max_depth) {
-                    const bool cosine = cam.importance_sampling != 0;
-                    const int split = (depth == 0 && cam.splitting_factor > 1) ? cam.splitting_factor : 1;
-                    const V no = add(p, scl(normal, seps));
-                    for (int b = split - 1; b >= 0; --b) {   // reverse push: branch 0 is walked first
-                        V wi;
-                        float pdf;
-                        if (split > 1)
-                            sample_hemisphere(cosine, rnd(key, DIM_SPLIT + 2 * b), rnd(key, DIM_SPLIT + 2 * b + 1), normal, helper_x, wi, pdf);
-                        else
-                            sample_hemisphere(cosine, rnd(key, DIM_HEMI_1), rnd(key, DIM_HEMI_2), normal, helper_x, wi, pdf);
-                        ++c.secondary;   // the reference traces the bounce even when its pdf rejects the contribution
-                        float ndotl = max_std(dot(normal, wi), 0.0f);
-                        V w = mk(0, 0, 0);
-                        if (pdf > 1e-6f) w = scl(scl(kd, 1.0f / 3.14159265359f), rt_div(ndotl, pdf));
-                        w = scl(w, rt_div(1.0f, (float)split));
-                        if (rr_prob < 1.0f && rr_prob > 0.0f) w = scl(w, rt_div(1.0f, rr_prob));
-                        PathItem &n = stack[++top];
-                        n.o = no;
-                        n.d = wi;
-                        n.thr = mul(thr, w);
-                        n.key = child_key(key, BRANCH_BOUNCE + b);
-                        n.depth_flags = (depth + 1) | ((int)culling << 16) | (1 << 17);
                     }
                 }
             }
-            if (cam.sample_max_val > 0.0f) {
-                sample.x = min_std(sample.x, cam.sample_max_val);
-                sample.y = min_std(sample.y, cam.sample_max_val);
-                sample.z = min_std(sample.z, cam.sample_max_val);
-            }
-            acc0 += sample.x;
-            acc1 += sample.y;
-            acc2 += sample.z;
         }
-        const float ns = (float)lp.n_samples;
-        float *dst = out + ((size_t)j * cam.resx + i) * 3;
-        dst[0] = rt_div(acc0, ns);
-        dst[1] = rt_div(acc1, ns);
-        dst[2] = rt_div(acc2, ns);
-    }
-    // wave-level reduction of the ray counters, one atomic per wave and counter
-    uint32_t vals[9] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels};
+        // ---- append the vertex record ------------------------------------------------------------------------
+        {
+            const unsigned vi = wave_append(want_vertex, vcount);
+            if (want_vertex) {
+                if (vi >= W.capacity) {
+                    *W.overflow = 1u;
+                } else {
+                    W.vtx.p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
+                    W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
+                    W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(v_mat));
+                    W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot));
+                    W.vtx.ks_w[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, 0.f);
+                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
+                }
+            }
+        }
+        // ---- append child paths, one ballot round per child index -------------------------------------------------
+        int max_children = n_children;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (!COUNT && (k >= 3 && k <= 6)) continue;
-        uint32_t v = wave_sum(vals[k]);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(stats + k, (unsigned long long)v);
+        for (int off = 32; off > 0; off >>= 1) max_children = max(max_children, __shfl_xor(max_children, off, 64));
+        for (int r = 0; r < max_children; ++r) {
+            const bool want = r < n_children;
+            const unsigned ci = wave_append(want, next_count);
+            if (!want) continue;
+            ++c.secondary;
+            if (!diffuse) {
+                put_path(W, gen + 1, ci, c_o[r], c_d[r], time, c_thr[r], c_key[r], slot, c_df[r]);
+            } else {
+                const bool cosine = cam.importance_sampling != 0;
+                V wi;
+                float pdf;
+                if (n_children > 1)
+                    sample_hemisphere(cosine, rnd(key, DIM_SPLIT + 2 * r), rnd(key, DIM_SPLIT + 2 * r + 1), b_normal, b_helper_x, wi, pdf);
+                else
+                    sample_hemisphere(cosine, rnd(key, DIM_HEMI_1), rnd(key, DIM_HEMI_2), b_normal, b_helper_x, wi, pdf);
+                float ndotl = max_std(dot(b_normal, wi), 0.0f);
+                V w = mk(0, 0, 0);
+                if (pdf > 1e-6f) w = scl(scl(b_kd, 1.0f / 3.14159265359f), rt_div(ndotl, pdf));
+                w = scl(w, rt_div(1.0f, (float)n_children));
+                if (b_rr < 1.0f && b_rr > 0.0f) w = scl(w, rt_div(1.0f, b_rr));
+                put_path(W, gen + 1, ci, b_origin, wi, time, mul(b_thr, w), child_key(key, BRANCH_BOUNCE + r), slot,
+                         (depth + 1) | ((int)culling << 16) | (1 << 17));
+            }
+        }
     }
+    flush_counters(c, stats, false);
 }
 
-// Primary visibility only: first sample's ray of each pixel, closest hit (time 0).
+// ---- direct: the light loop of calculate_color (src/ray_trace.cpp:182-400) -------------------------------------
+// k_pad lanes (a power of two <= 64) share one vertex; lane kl evaluates light samples kl, kl + k_pad, ...
+// `light_of` maps a light-sample number to its light.  The per-vertex sum is a fixed-shape shuffle tree.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) direct_kernel(DevScene S, Wavefront W, int gen, const int *__restrict__ light_of, int k_total, int k_pad,
+                                                      unsigned long long *__restrict__ stats) {
+    unsigned nv = W.vertex_count[gen];
+    if (nv > W.capacity) nv = W.capacity;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned vpw = 64u / (unsigned)k_pad;   // vertices per wave
+    const unsigned wave_global = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const unsigned n_waves = (gridDim.x * 256u) >> 6;
+    const unsigned kl = lane & (unsigned)(k_pad - 1);
+    Counters c;
+    memset(&c, 0, sizeof c);
+    const float seps = S.seps;
+    for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
+        const unsigned v = vbase + lane / (unsigned)k_pad;
+        V sum = mk(0, 0, 0);
+        int slot = 0;
+        V weight = mk(0, 0, 0);
+        if (v < nv) {
+            const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v], kds = W.vtx.kd_slot[v], ksw = W.vtx.ks_w[v],
+                         ww = W.vtx.weight[v];
+            const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z);
+            const V kd = mk(kds.x, kds.y, kds.z), ks = mk(ksw.x, ksw.y, ksw.z);
+            const uint32_t key = __float_as_uint(nk.w);
+            const rt_material &m = S.materials[__float_as_int(vm.w)];
+            slot = __float_as_int(kds.w);
+            weight = mk(ww.x, ww.y, ww.z);
+            const float time = pt.w;
+            for (unsigned k = kl; k < (unsigned)k_total; k += (unsigned)k_pad) {
+                const int li = light_of[k];
+                const rt_light &L = S.lights[li];
+                const float lw = rt_div(1.0f, (float)L.samples);
+                float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
+                V rad, ldir;
+                float dist;
+                light_sample(S, L, p, normal, r1, r2, rad, ldir, dist, c);
+                if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
+                V so = add(p, scl(ldir, seps));
+                ++c.shadow;
+                Hit sh = traverse<true, COUNT>(S, so, ldir, time, false, seps, dist, c);
+                if (sh.prim != -1 && sh.t < dist - seps) continue;
+                V fd, fs;
+                brdf_terms(m, normal, ldir, view, kd, ks, fd, fs);
+                fd = scl(mul(fd, rad), lw);
+                fs = scl(mul(fs, rad), lw);
+                sum = add(sum, fd);
+                sum = add(sum, fs);
+            }
+        }
+        for (int off = k_pad >> 1; off > 0; off >>= 1) {
+            sum.x += __shfl_xor(sum.x, off, 64);
+            sum.y += __shfl_xor(sum.y, off, 64);
+            sum.z += __shfl_xor(sum.z, off, 64);
+        }
+        if (v < nv && kl == 0) accum_add(W.accum, slot, mul(weight, sum));
+    }
+    flush_counters(c, stats, COUNT);
+}
+
+// ---- resolve: per-sample clamp (src/ray_trace.cpp:1158-1167) and the pixel mean (src/main.cpp:464-483) --------------
+__global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch b, Wavefront W, float *__restrict__ out) {
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= b.n_pixels) return;
+    int i, j;
+    batch_pixel(b, pl, i, j);
+    if (i >= cam.resx || j >= cam.resy) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int s = 0; s < b.n_samples; ++s) {
+        const float *src = W.accum + 3 * ((size_t)s * b.n_pixels + pl);
+        float r = src[0], g = src[1], bl = src[2];
+        if (cam.sample_max_val > 0.0f) {
+            r = min_std(r, cam.sample_max_val);
+            g = min_std(g, cam.sample_max_val);
+            bl = min_std(bl, cam.sample_max_val);
+        }
+        a0 += r;
+        a1 += g;
+        a2 += bl;
+    }
+    const float ns = (float)b.n_samples;
+    float *dst = out + ((size_t)j * cam.resx + i) * 3;
+    dst[0] = rt_div(a0, ns);
+    dst[1] = rt_div(a1, ns);
+    dst[2] = rt_div(a2, ns);
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(256) primary_kernel(DevScene S, rt_camera_desc cam, int grid_n, int32_t *__restrict__ shape_out,
                                                        int32_t *__restrict__ id_out, float *__restrict__ t_out,
@@ -1330,7 +681,51 @@ struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // wavefront state (allocated on first render, kept)
+    Wavefront wf{};
+    std::vector<void *> wf_allocations;
+    unsigned *host_flags = nullptr;   // pinned: overflow flag read back per batch
+    int *light_of = nullptr;          // light-sample number -> light index
+    int k_total = 0, k_pad = 1;
+    bool has_dielectric = false;
 };
+
+// Entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides; ~220 bytes of HBM each).
+static unsigned wavefront_capacity() {
+    if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
+        long v = atol(e);
+        if (v >= 4096 && v <= (1l << 28)) return (unsigned)v;
+    }
+    return 1u << 23;
+}
+
+static int ensure_wavefront(rt_scene *s) {
+    if (s->wf.capacity) return 0;
+    const unsigned cap = wavefront_capacity();
+    Wavefront W{};
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        HIP_OK(hipMalloc(p, bytes));
+        s->wf_allocations.push_back(*p);
+        return 0;
+    };
+    for (int k = 0; k < 2; ++k) {
+        if (alloc((void **)&W.q[k].o_time, (size_t)cap * 16) || alloc((void **)&W.q[k].d_key, (size_t)cap * 16) ||
+            alloc((void **)&W.q[k].thr_slot, (size_t)cap * 16) || alloc((void **)&W.q[k].depth_flags, (size_t)cap * 4))
+            return 10;
+    }
+    if (alloc((void **)&W.hit_t, (size_t)cap * 4) || alloc((void **)&W.hit_prim, (size_t)cap * 4) ||
+        alloc((void **)&W.vtx.p_time, (size_t)cap * 16) || alloc((void **)&W.vtx.n_key, (size_t)cap * 16) ||
+        alloc((void **)&W.vtx.view_mat, (size_t)cap * 16) || alloc((void **)&W.vtx.kd_slot, (size_t)cap * 16) ||
+        alloc((void **)&W.vtx.ks_w, (size_t)cap * 16) || alloc((void **)&W.vtx.weight, (size_t)cap * 16) ||
+        alloc((void **)&W.accum, (size_t)cap * 12) || alloc((void **)&W.path_count, (2 * (MAX_GENERATIONS + 1) + 1) * sizeof(unsigned)))
+        return 10;
+    W.vertex_count = W.path_count + (MAX_GENERATIONS + 1);
+    W.overflow = W.path_count + 2 * (MAX_GENERATIONS + 1);
+    W.capacity = cap;
+    HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
+    s->wf = W;
+    return 0;
+}
 
 extern "C" {
 
@@ -1523,6 +918,20 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         rt_scene_destroy(s);
         return 10;
     }
+    {   // light-sample numbering of calculate_color's double loop (src/ray_trace.cpp:182-187)
+        std::vector<int> light_of;
+        for (int i = 0; i < d->n_lights; ++i)
+            for (int k = 0; k < d->lights[i].samples; ++k) light_of.push_back(i);
+        s->k_total = (int)light_of.size();
+        s->k_pad = 1;
+        while (s->k_pad < s->k_total && s->k_pad < 64) s->k_pad <<= 1;
+        if (upload<int>(light_of.data(), light_of.size(), &s->light_of)) {
+            rt_scene_destroy(s);
+            return 10;
+        }
+        keep(s->light_of);
+        for (int i = 0; i < d->n_materials; ++i) s->has_dielectric |= d->materials[i].type == RT_MAT_DIELECTRIC;
+    }
     *out = s;
     return 0;
 }
@@ -1530,6 +939,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
     for (void *p : s->allocations) (void)hipFree(p);
+    for (void *p : s->wf_allocations) (void)hipFree(p);
+    if (s->host_flags) (void)hipHostFree(s->host_flags);
     if (s->stats) (void)hipFree(s->stats);
     if (s->framebuffer) (void)hipFree(s->framebuffer);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1555,14 +966,12 @@ static int check_camera(const rt_scene *s, const rt_camera_desc *cam, int &grid_
         grid_n = (int)sqrt((double)cam->num_samples);   // src/camera.cpp:149
         n_samples = grid_n * grid_n;
     }
-    int split = cam->splitting_factor > 1 ? cam->splitting_factor : 1;
-    // pending-ray stack bound: at most one extra item per depth level, plus the depth-0 split fan-out
-    if ((int)s->dev.max_depth + 2 + split > PATH_STACK) {
-        g_error = "MaxRecursionDepth + SplittingFactor exceeds the per-lane path stack (" + std::to_string(PATH_STACK) + ")";
+    if (!(s->dev.max_depth <= (float)(MAX_GENERATIONS - 2))) {
+        g_error = "MaxRecursionDepth exceeds the supported " + std::to_string(MAX_GENERATIONS - 2) + " queue generations";
         return 5;
     }
-    if (s->dev.max_depth > 60000.f) {
-        g_error = "MaxRecursionDepth too large";
+    if (cam->splitting_factor > 4096) {
+        g_error = "SplittingFactor too large";
         return 5;
     }
     return 0;
@@ -1599,15 +1008,15 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_OK(hipSetDevice(s->device));
-    LaunchParams lp;
-    lp.tiles_x = (cam->resx + TILE - 1) / TILE;
-    lp.tiles_y = (cam->resy + TILE - 1) / TILE;
-    lp.rank = rank;
-    lp.world = world;
-    const int total_tiles = lp.tiles_x * lp.tiles_y;
-    lp.n_owned = total_tiles > rank ? (total_tiles - rank + world - 1) / world : 0;
-    lp.grid_n = grid_n;
-    lp.n_samples = n_samples;
+    if (int rc = ensure_wavefront(s)) return rc;
+    const Wavefront &W = s->wf;
+    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
+    const int total_tiles = tiles_x * tiles_y;
+    const int n_owned = total_tiles > rank ? (total_tiles - rank + world - 1) / world : 0;
+    if ((unsigned long long)n_samples * 1024ull > W.capacity) {
+        g_error = "NumSamples too large for the wavefront capacity (set RT_WAVEFRONT_CAPACITY)";
+        return 5;
+    }
 
     // output: device pointer -> write in place; host pointer -> internal framebuffer + copy back
     hipPointerAttribute_t attr;
@@ -1629,13 +1038,62 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     }
     HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
-    if (lp.n_owned > 0) {
-        dim3 grid((unsigned)lp.n_owned * 4), block(BLOCK_EDGE * BLOCK_EDGE);
-        if (s->counters)
-            hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, s->stream, s->dev, *cam, lp, dev_out, s->stats);
-        else
-            hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, s->stream, s->dev, *cam, lp, dev_out, s->stats);
+
+    const bool pt = cam->path_tracing != 0;
+    const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
+    // queue growth bound per camera sample: splitting fans out at depth 0, dielectrics may double per bounce
+    unsigned growth = (unsigned)(pt && cam->splitting_factor > 1 ? cam->splitting_factor : 1) * (s->has_dielectric ? 2u : 1u);
+    const unsigned grid_cap = 4096;
+    int tile = 0;
+    while (tile < n_owned) {
+        unsigned long long slots_max = W.capacity / growth;
+        long long per_tile = 1024ll * n_samples;
+        int tiles_now = (int)std::min<long long>(n_owned - tile, std::max<long long>(1, (long long)slots_max / per_tile));
+        Batch b;
+        b.tile_first = tile;
+        b.tile_count = tiles_now;
+        b.n_pixels = tiles_now * 1024;
+        b.n_samples = n_samples;
+        b.grid_n = grid_n;
+        b.tiles_x = tiles_x;
+        b.rank = rank;
+        b.world = world;
+        const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
+        HIP_OK(hipMemsetAsync(W.path_count, 0, (2 * (MAX_GENERATIONS + 1) + 1) * sizeof(unsigned), s->stream));
+        hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
+        const unsigned grid = std::min<unsigned>(grid_cap, (unsigned)((std::min<unsigned long long>(W.capacity, (unsigned long long)slots * growth) + 255) / 256));
+        for (int gen = 0; gen < n_gen; ++gen) {
+            if (s->counters)
+                hipLaunchKernelGGL(closest_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pt ? 0 : 1, s->stats);
+            else
+                hipLaunchKernelGGL(closest_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pt ? 0 : 1, s->stats);
+            if (pt)
+                hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+            else
+                hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+            if (s->k_total > 0) {
+                if (s->counters)
+                    hipLaunchKernelGGL(direct_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->light_of, s->k_total, s->k_pad, s->stats);
+                else
+                    hipLaunchKernelGGL(direct_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->light_of, s->k_total, s->k_pad, s->stats);
+            }
+        }
+        hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
         HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        HIP_OK(hipStreamSynchronize(s->stream));
+        if (*s->host_flags) {   // a queue ran out of room: redo this batch with fewer camera samples in flight
+            if (tiles_now == 1 && (unsigned long long)per_tile * growth > W.capacity) {
+                g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
+                return 6;
+            }
+            growth *= 2;
+            // ray counters of the abandoned attempt are not separable; the frame's counters restart
+            HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
+            tile = 0;
+            continue;
+        }
+        tile += tiles_now;
     }
     HIP_OK(hipEventRecord(s->ev1, s->stream));
     if (!out_on_device) HIP_OK(hipMemcpyAsync(hdr_out, dev_out, n_floats * sizeof(float), hipMemcpyDeviceToHost, s->stream));

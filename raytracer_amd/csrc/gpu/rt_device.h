@@ -1,0 +1,899 @@
+// Device-side scene access of the rendering core: BVH traversal (closest / any hit), primitive tests, surface
+// queries, textures, lights, direction sampling and the camera.  Every function cites the reference routine it
+// restates; the arithmetic order is part of the definition (see rt_math.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gpu_render.h"
+#include "rt_math.h"
+
+namespace rt {
+
+constexpr int TILE = 32;              // image tile edge used for sharding
+constexpr int TRAVERSAL_STACK = 64;   // src/bvh.cpp:423
+
+enum {
+    DIM_REFLECT_XI1 = 0, DIM_REFLECT_XI2 = 1, DIM_REFRACT_XI1 = 2, DIM_REFRACT_XI2 = 3, DIM_RR = 4, DIM_HEMI_1 = 5, DIM_HEMI_2 = 6,
+    DIM_SPLIT = 8, DIM_LIGHT = 4096,
+    DIM_CAM_R1 = 0, DIM_CAM_R2 = 1, DIM_CAM_R3 = 2, DIM_CAM_R4 = 3, DIM_CAM_TIME = 4,
+    BRANCH_ROOT = 0, BRANCH_REFLECT = 1, BRANCH_REFRACT = 2, BRANCH_BOUNCE = 3
+};
+
+// ---- device-resident scene -------------------------------------------------------------------
+// nodes:  2 x float4 per BVH node  {bmin.xyz, bits(offset)} {bmax.xyz, bits(n_prims | axis << 16)}
+// prims:  3 x float4 per leaf entry, in leaf order:
+//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), bits(shape), bits(ref id)}
+//         sphere   {...unused...}                 {0, bits(-1 - sphere), bits(shape), bits(123456)}
+// inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
+//         flags bit0 = identity transform, bit1 = has motion blur
+struct DevScene {
+    const float4 *nodes;
+    const float4 *prims;
+    const float4 *inst;
+    const rt_instance *instances;
+    const rt_triangle *triangles;
+    const float *flat_normals;
+    const rt_sphere *spheres;
+    const rt_plane *planes;
+    const rt_material *materials;
+    const rt_texture *textures;
+    const int32_t *texture_refs;
+    const rt_image *images;
+    const uint8_t *texels_u8;
+    const float *texels_f32;
+    const rt_light *lights;
+    int n_triangles, n_spheres, n_planes, n_lights, n_nodes;
+    float ieps, seps, max_depth;
+    float ambient[3], bg[3];
+    int bg_tex, is_probe;
+};
+
+struct Counters {   // per-lane, reduced per wave at kernel end
+    uint32_t primary, shadow, secondary, shaded;
+    uint32_t nodes, tri, sph, pln, texels;
+};
+
+struct Hit {
+    float t;
+    int prim;   // >= 0 leaf entry; <= -2 plane (-2 - index); -1 none
+};
+
+// ---- traversal ---------------------------------------------------------------------------------
+// bvh::intersect (src/bvh.cpp:383-480) with intersect_aabb_fast (:348-381): planes first, then an
+// ordered stack traversal (near child first by the sign of the ray direction on the split axis).
+// A hit replaces the current one only if t > eps and t < t_hit, so of equal-distance hits the one
+// found first in this order is kept.
+template <bool ANY, bool COUNT>
+__device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, float eps, float stop_t, Counters &c) {
+    Hit h;
+    h.t = stop_t;
+    h.prim = -1;
+    for (int pi = 0; pi < S.n_planes; ++pi) {   // plane::intersect, src/shapes.cpp:506-527
+        if (COUNT) ++c.pln;
+        const rt_plane &p = S.planes[pi];
+        V n = mk(p.normal);
+        float denom = dot(n, d);
+        if (absf(denom) < eps) continue;
+        float num = dot(sub(mk(p.point), o), n);
+        float tc = rt_div(num, denom);
+        if (tc < eps) continue;
+        if (tc > eps && tc < h.t) {
+            h.t = tc;
+            h.prim = -2 - pi;
+            if (ANY) return h;
+        }
+    }
+    if (S.n_nodes == 0) return h;
+    const float ix = rt_div(1.0f, d.x), iy = rt_div(1.0f, d.y), iz = rt_div(1.0f, d.z);
+    const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
+    int stack[TRAVERSAL_STACK];
+    int top = 0;
+    stack[0] = 0;
+    int cur_inst = -1;   // placement whose object-space ray is cached in oo/dd
+    V oo = o, dd = d;
+    while (top >= 0) {
+        const int ni = stack[top--];
+        const float4 n0 = S.nodes[2 * ni], n1 = S.nodes[2 * ni + 1];
+        if (COUNT) ++c.nodes;
+        float tmin = ((nx ? n1.x : n0.x) - o.x) * ix;
+        float tmax = ((nx ? n0.x : n1.x) - o.x) * ix;
+        const float tymin = ((ny ? n1.y : n0.y) - o.y) * iy;
+        const float tymax = ((ny ? n0.y : n1.y) - o.y) * iy;
+        if ((tmin > tymax) || (tymin > tmax)) continue;
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        const float tzmin = ((nz ? n1.z : n0.z) - o.z) * iz;
+        const float tzmax = ((nz ? n0.z : n1.z) - o.z) * iz;
+        if ((tmin > tzmax) || (tzmin > tmax)) continue;
+        if (tzmin > tmin) tmin = tzmin;
+        if (tzmax < tmax) tmax = tzmax;
+        if (!((tmin < h.t) && (tmax > 0.0f))) continue;
+        const int offset = __float_as_int(n0.w);
+        const int meta = __float_as_int(n1.w);
+        const int nprims = meta & 0xffff;
+        if (nprims > 0) {
+            for (int i = 0; i < nprims; ++i) {
+                const int k = offset + i;
+                const float4 p2 = S.prims[3 * k + 2];
+                const int inst = __float_as_int(p2.y);
+                float tc;
+                if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
+                    if (COUNT) ++c.tri;
+                    const float4 p0 = S.prims[3 * k], p1 = S.prims[3 * k + 1];
+                    if (inst != cur_inst) {
+                        cur_inst = inst;
+                        const float4 r3 = S.inst[4 * inst + 3];
+                        const int flags = __float_as_int(r3.w);
+                        V moved = o;
+                        if (flags & 2) moved = sub(o, scl(mk(r3.x, r3.y, r3.z), time));
+                        if (flags & 1) {
+                            oo = moved;
+                            dd = d;
+                        } else {
+                            const float4 r0 = S.inst[4 * inst], r1 = S.inst[4 * inst + 1], r2 = S.inst[4 * inst + 2];
+                            oo = mk((r0.x * moved.x + r0.y * moved.y) + (r0.z * moved.z + r0.w),
+                                    (r1.x * moved.x + r1.y * moved.y) + (r1.z * moved.z + r1.w),
+                                    (r2.x * moved.x + r2.y * moved.y) + (r2.z * moved.z + r2.w));
+                            dd = mk((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z,
+                                    (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
+                        }
+                    }
+                    const V c1s = mk(p0.x, p0.y, p0.z), e1 = mk(p0.w, p1.x, p1.y), e2 = mk(p1.z, p1.w, p2.x);
+                    const V os = scl(oo, 1000.0f);
+                    const V hh = cross(dd, e2);
+                    const float det = dot(e1, hh);
+                    if (culling) {
+                        if (det < eps) continue;
+                    } else {
+                        if (absf(det) < eps) continue;
+                    }
+                    const float f = rt_div(1.0f, det);
+                    const V s = sub(os, c1s);
+                    float u = dot(s, hh);
+                    u *= f;
+                    if (u < (0.0f - eps) || u > (1.0f + eps)) continue;
+                    const V q = cross(s, e1);
+                    float v = dot(dd, q);
+                    v *= f;
+                    if (v < (0.0f - eps) || (u + v) > (1.0f + eps)) continue;
+                    tc = dot(e2, q);
+                    tc *= f;
+                    tc *= (1.0f / 1000.0f);
+                    if (!(tc > eps)) continue;
+                } else {   // sphere::intersect, src/shapes.cpp:407-447
+                    if (COUNT) ++c.sph;
+                    const rt_sphere &sp = S.spheres[-1 - inst];
+                    const V so = xpoint(sp.inv_model, o);
+                    const V sd = xdir(sp.inv_model, d);
+                    const V oc = sub(so, mk(sp.center));
+                    const float a = dot(sd, sd);
+                    float b = dot(oc, sd);
+                    b *= 2.0f;
+                    float cc = dot(oc, oc);
+                    cc -= (sp.radius * sp.radius);
+                    const float disc = b * b - 4 * a * cc;
+                    if (disc < 0.0f) continue;
+                    const float sq = rt_sqrt(disc);
+                    const float inv2a = rt_div(1.0f, 2.0f * a);
+                    const float t1 = (-b - sq) * inv2a, t2 = (-b + sq) * inv2a;
+                    if (t1 > eps)
+                        tc = t1;
+                    else if (t2 > eps)
+                        tc = t2;
+                    else
+                        continue;
+                }
+                if (tc > eps && tc < h.t) {
+                    h.t = tc;
+                    h.prim = k;
+                    if (ANY) return h;
+                }
+            }
+        } else {
+            const int axis = meta >> 16;
+            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+            const int near_i = neg ? offset : ni + 1;
+            const int far_i = neg ? ni + 1 : offset;
+            stack[++top] = far_i;
+            stack[++top] = near_i;
+        }
+    }
+    return h;
+}
+
+// ---- hit decoding -----------------------------------------------------------------------------
+struct Surface {
+    int kind;       // 0 triangle, 1 sphere, 2 plane
+    int index;      // triangle / sphere / plane index
+    int instance;   // placement (triangles)
+    int material;
+    int toff, tcount;
+};
+
+__device__ Surface surface_of(const DevScene &S, const Hit &h) {
+    Surface s;
+    if (h.prim <= -2) {
+        s.kind = 2;
+        s.index = -2 - h.prim;
+        s.instance = -1;
+        const rt_plane &p = S.planes[s.index];
+        s.material = p.material;
+        s.toff = p.tex_offset;
+        s.tcount = p.tex_count;
+        return s;
+    }
+    const float4 p2 = S.prims[3 * h.prim + 2];
+    const int inst = __float_as_int(p2.y);
+    if (inst >= 0) {
+        s.kind = 0;
+        s.index = __float_as_int(p2.z);
+        s.instance = inst;
+        const rt_instance &in = S.instances[inst];
+        s.material = in.material;
+        s.toff = in.tex_offset;
+        s.tcount = in.tex_count;
+    } else {
+        s.kind = 1;
+        s.index = -1 - inst;
+        s.instance = -1;
+        const rt_sphere &sp = S.spheres[s.index];
+        s.material = sp.material;
+        s.toff = sp.tex_offset;
+        s.tcount = sp.tex_count;
+    }
+    return s;
+}
+
+// get_normal: triangle src/shapes.cpp:152-197, sphere :390-405, plane :504
+__device__ V normal_of(const DevScene &S, const Surface &s, V p) {
+    if (s.kind == 0) {
+        const rt_triangle &t = S.triangles[s.index];
+        const rt_instance &in = S.instances[s.instance];
+        if (!t.smooth) return normalize(xdir(in.normal, mk(S.flat_normals + 3 * s.index)));
+        V po = xpoint(in.inv_model, p);
+        V c1 = mk(t.c1);
+        V v0 = sub(mk(t.c2), c1), v1 = sub(mk(t.c3), c1), v2 = sub(po, c1);
+        float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+        const float denom = d00 * d11 - d01 * d01;
+        float v = rt_div(d11 * d20 - d01 * d21, denom);
+        float w = rt_div(d00 * d21 - d01 * d20, denom);
+        float u = 1.0f - v - w;
+        V n = add(add(scl(mk(t.n1), u), scl(mk(t.n2), v)), scl(mk(t.n3), w));
+        n = normalize(n);
+        return normalize(xdir(in.normal, n));
+    }
+    if (s.kind == 1) {
+        const rt_sphere &sp = S.spheres[s.index];
+        V po = xpoint(sp.inv_model, p);
+        return normalize(xdir(sp.normal, sub(po, mk(sp.center))));
+    }
+    return mk(S.planes[s.index].normal);
+}
+
+// calculate_uv: triangle src/shapes.cpp:87-122, sphere :449-465, plane :529-548
+__device__ void uv_of(const DevScene &S, const Surface &s, V p, float &u, float &v) {
+    if (s.kind == 0) {
+        const rt_triangle &t = S.triangles[s.index];
+        const rt_instance &in = S.instances[s.instance];
+        V local = xpoint(in.inv_model, p);
+        V c1 = mk(t.c1);
+        V e1 = sub(mk(t.c2), c1), e2 = sub(mk(t.c3), c1), vp = sub(local, c1);
+        float d00 = dot(e1, e1), d01 = dot(e1, e2), d11 = dot(e2, e2), d20 = dot(vp, e1), d21 = dot(vp, e2);
+        float denom = d00 * d11 - d01 * d01;
+        if (absf(denom) < 1e-10f) {
+            u = 0.0f;
+            v = 0.0f;
+            return;
+        }
+        float inv = rt_div(1.0f, denom);
+        float beta = (d11 * d20 - d01 * d21) * inv;
+        float gamma = (d00 * d21 - d01 * d20) * inv;
+        float alpha = 1.0f - beta - gamma;
+        u = alpha * t.tex_u[0] + beta * t.tex_u[1] + gamma * t.tex_u[2];
+        v = alpha * t.tex_v[0] + beta * t.tex_v[1] + gamma * t.tex_v[2];
+        return;
+    }
+    if (s.kind == 1) {
+        const rt_sphere &sp = S.spheres[s.index];
+        V q = normalize(sub(xpoint(sp.inv_model, p), mk(sp.center)));
+        float phi = rt_atan2(q.z, q.x);
+        float theta = rt_asin(q.y);
+        const float PI = 3.14159265359f;
+        u = 1.0f - rt_div(phi + PI, 2.0f * PI);
+        v = 1.0f - rt_div(theta + PI / 2.0f, PI);
+        return;
+    }
+    const rt_plane &pl = S.planes[s.index];
+    V n = mk(pl.normal);
+    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+    V tangent = normalize(cross(n, helper));
+    V bitangent = cross(n, tangent);
+    V to = sub(p, mk(pl.point));
+    u = dot(to, tangent);
+    v = dot(to, bitangent);
+}
+
+// get_tangent: triangle src/shapes.cpp:281-316, sphere :467-494, plane :550-562
+__device__ V tangent_of(const DevScene &S, const Surface &s, V p) {
+    if (s.kind == 0) {
+        const rt_triangle &t = S.triangles[s.index];
+        const rt_instance &in = S.instances[s.instance];
+        V c1 = mk(t.c1);
+        V e1 = sub(mk(t.c2), c1), e2 = sub(mk(t.c3), c1);
+        float du1 = t.tex_u[1] - t.tex_u[0], dv1 = t.tex_v[1] - t.tex_v[0];
+        float du2 = t.tex_u[2] - t.tex_u[0], dv2 = t.tex_v[2] - t.tex_v[0];
+        float det = (du1 * dv2 - du2 * dv1);
+        V lt;
+        if (absf(det) < 1e-8f) {
+            lt = e1;
+        } else {
+            float f = rt_div(1.0f, det);
+            lt = scl(sub(scl(e1, dv2), scl(e2, dv1)), f);
+        }
+        return normalize(xdir(in.model, lt));
+    }
+    if (s.kind == 1) {
+        // the reference's object-space sphere tangent is always (1, 0, 0): src/shapes.cpp:473-487 reads scalar
+        // copies of a difference vector that only exists in SIMD lanes
+        return normalize(xdir(S.spheres[s.index].model, mk(1, 0, 0)));
+    }
+    const rt_plane &pl = S.planes[s.index];
+    V helper = absf(pl.raw_normal_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+    return normalize(cross(mk(pl.normal), helper));
+}
+
+// ---- textures (src/texture.cpp) ------------------------------------------------------------------
+__device__ bool image_sample(const DevScene &S, const rt_image &im, bool bilinear, float u, float v, V &color, Counters &c) {
+    if (im.width <= 0 || im.height <= 0) return false;
+    const int W = im.width, H = im.height;
+    u -= floorf(u);
+    v -= floorf(v);
+    if (!bilinear) {   // image::sample_nearest :64-93
+        int x = (int)(u * W), y = (int)(v * H);
+        if (x >= W) x = W - 1;
+        if (y >= H) y = H - 1;
+        ++c.texels;
+        if (im.is_hdr) {
+            const float *p = S.texels_f32 + (size_t)im.offset + ((size_t)y * W + x) * 4;
+            color = mk(p[0], p[1], p[2]);
+        } else {
+            const uint8_t *p = S.texels_u8 + (size_t)im.offset + ((size_t)y * W + x) * 3;
+            color = mk(p[0] * (1.0f / 255.0f), p[1] * (1.0f / 255.0f), p[2] * (1.0f / 255.0f));
+        }
+        return true;
+    }
+    // image::sample_bilinear :95-166
+    float px = u * W - 0.5f, py = v * H - 0.5f;
+    int x = (int)floorf(px), y = (int)floorf(py);
+    float ur = px - x, vr = py - y;
+    float uo = 1.0f - ur, vo = 1.0f - vr;
+    int x0 = (x % W + W) % W, x1 = ((x + 1) % W + W) % W;
+    int y0 = (y % H + H) % H, y1 = ((y + 1) % H + H) % H;
+    c.texels += 4;
+    float out[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float v00, v10, v01, v11;
+        if (im.is_hdr) {
+            const float *b = S.texels_f32 + (size_t)im.offset;
+            v00 = b[((size_t)y0 * W + x0) * 4 + ch];
+            v10 = b[((size_t)y0 * W + x1) * 4 + ch];
+            v01 = b[((size_t)y1 * W + x0) * 4 + ch];
+            v11 = b[((size_t)y1 * W + x1) * 4 + ch];
+        } else {
+            const uint8_t *b = S.texels_u8 + (size_t)im.offset;
+            v00 = b[((size_t)y0 * W + x0) * 3 + ch];
+            v10 = b[((size_t)y0 * W + x1) * 3 + ch];
+            v01 = b[((size_t)y1 * W + x0) * 3 + ch];
+            v11 = b[((size_t)y1 * W + x1) * 3 + ch];
+        }
+        float top = v00 * uo + v10 * ur;
+        float bot = v01 * uo + v11 * ur;
+        out[ch] = top * vo + bot * vr;
+    }
+    if (im.is_hdr)
+        color = mk(out[0], out[1], out[2]);
+    else
+        color = mk(out[0] * (1.0f / 255.0f), out[1] * (1.0f / 255.0f), out[2] * (1.0f / 255.0f));
+    return true;
+}
+
+__constant__ uint8_t PERLIN_P[256] = {   // Ken Perlin's reference permutation (src/texture.cpp:238)
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,  37,  240,
+    21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,  57,  177, 33,  88,
+    237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111,
+    229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,
+    209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217,
+    226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,
+    223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,
+    108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241,
+    81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,
+    150, 254, 138, 236, 205, 93,  222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+
+__device__ __forceinline__ float pfade(float t) { return t * t * t * (t * (t * 6 - 15) + 10); }
+__device__ __forceinline__ float plerp(float t, float a, float b) { return a + t * (b - a); }
+__device__ __forceinline__ float pgrad(int hash, float x, float y, float z) {
+    int h = hash & 15;
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : (h == 12 || h == 14 ? x : z);
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ float perlin_noise(float x, float y, float z) {   // Perlin::noise :204-223
+    auto p = [](int i) -> int { return PERLIN_P[i & 255]; };
+    int X = (int)floorf(x) & 255, Y = (int)floorf(y) & 255, Z = (int)floorf(z) & 255;
+    x -= floorf(x);
+    y -= floorf(y);
+    z -= floorf(z);
+    float u = pfade(x), v = pfade(y), w = pfade(z);
+    int A = p(X) + Y, AA = p(A) + Z, AB = p(A + 1) + Z;
+    int B = p(X + 1) + Y, BA = p(B) + Z, BB = p(B + 1) + Z;
+    return plerp(w,
+                 plerp(v, plerp(u, pgrad(p(AA), x, y, z), pgrad(p(BA), x - 1, y, z)),
+                       plerp(u, pgrad(p(AB), x, y - 1, z), pgrad(p(BB), x - 1, y - 1, z))),
+                 plerp(v, plerp(u, pgrad(p(AA + 1), x, y, z - 1), pgrad(p(BA + 1), x - 1, y, z - 1)),
+                       plerp(u, pgrad(p(AB + 1), x, y - 1, z - 1), pgrad(p(BB + 1), x - 1, y - 1, z - 1))));
+}
+__device__ float perlin(V h, const rt_texture &t) {   // perlin() :241-274
+    float s = 0.0f;
+    float x = h.x * t.noise_scale, y = h.y * t.noise_scale, z = h.z * t.noise_scale;
+    float weight = 1.0f, max_amp = 0.0f;
+    int K = (int)t.num_octaves;
+    if (K < 1) K = 1;
+    for (int k = 0; k < K; ++k) {
+        s += weight * perlin_noise(x, y, z);
+        max_amp += weight;
+        x *= 2.0f;
+        y *= 2.0f;
+        weight *= 0.5f;
+    }
+    float sn = rt_div(s, max_amp);
+    if (t.noise_conversion == RT_NOISE_ABSVAL) return absf(sn);
+    return (sn + 1.0f) * 0.5f;
+}
+// texture::sample :168-197
+__device__ void tex_sample(const DevScene &S, const rt_texture &t, float u, float v, V h, V &color, Counters &c) {
+    if (t.image >= 0) {
+        image_sample(S, S.images[t.image], t.interp != RT_INTERP_NEAREST, u, v, color, c);
+    } else if (t.kind == RT_TEX_CHECKER) {
+        int x = (int)floorf((u + t.offset) * t.scale);
+        int y = (int)floorf((v + t.offset) * t.scale);
+        color = ((x + y) % 2 != 0) ? mk(t.black) : mk(t.white);
+    } else {
+        float x = perlin(h, t);
+        color = mk(x, x, x);
+    }
+}
+
+// get_latlong_uv / get_probe_uv, src/ray_trace.cpp:7-39
+__device__ void latlong_uv(V d, float &u, float &v) {
+    const float pi = 3.14159265359f;
+    u = (1.0f + rt_div(rt_atan2(d.x, -d.z), pi)) * 0.5f;
+    v = rt_div(rt_acos(d.y), pi);
+}
+__device__ void probe_uv(V d, float &u, float &v) {
+    const float pi = 3.14159265359f;
+    float len_sq = d.x * d.x + d.y * d.y;
+    float r = 0.0f;
+    if (len_sq > 1e-6f) r = rt_div((1.0f / pi) * rt_acos(-d.z), rt_sqrt(len_sq));
+    u = (r * d.x + 1.0f) * 0.5f;
+    v = (-r * d.y + 1.0f) * 0.5f;
+}
+// miss / depth-limit colour (src/ray_trace.cpp:649-679, 691-721, 887-903)
+__device__ V background(const DevScene &S, const rt_camera_desc &cam, V dir, bool whitted, float pixelu, float pixelv, Counters &c) {
+    if (S.bg_tex >= 0) {
+        const rt_texture &bg = S.textures[S.bg_tex];
+        if (bg.image >= 0) {
+            V color = mk(0, 0, 0);
+            if (!whitted || cam.is_hdr) {
+                float u, v;
+                if (S.is_probe)
+                    probe_uv(dir, u, v);
+                else
+                    latlong_uv(dir, u, v);
+                tex_sample(S, bg, u, v, mk(0, 0, 0), color, c);
+            } else {
+                tex_sample(S, bg, pixelu, pixelv, mk(pixelu, pixelv, 0), color, c);
+            }
+            return color;
+        }
+    }
+    return mk(S.bg);
+}
+
+// ---- directions (src/ray_trace.cpp:41-105, 408-492) ------------------------------------------------
+__device__ void sample_hemisphere(bool cosine, float r1, float r2, V normal, float helper_x, V &dir, float &pdf) {
+    float phi = 2.0f * 3.14159265359f * r1;
+    float sin_theta, cos_theta;
+    if (cosine) {
+        sin_theta = rt_sqrt(r2);
+        cos_theta = rt_sqrt(1.0f - r2);
+    } else {
+        sin_theta = rt_sqrt(1.0f - r2 * r2);
+        cos_theta = r2;
+    }
+    float x = sin_theta * rt_cos(phi), y = sin_theta * rt_sin(phi), z = cos_theta;
+    V w = normal;
+    V helper = absf(helper_x) > 0.9f ? mk(0, 1, 0) : mk(1, 0, 0);
+    V u = normalize(cross(helper, w));
+    V v = normalize(cross(w, u));
+    dir = normalize(add(add(scl(u, x), scl(v, y)), scl(w, z)));
+    pdf = cosine ? rt_div(cos_theta, 3.14159265359f) : 1.0f / (2.0f * 3.14159265359f);
+}
+__device__ void add_roughness(V &R, float roughness, float r_xi1, float r_xi2) {
+    float ax = absf(R.x), ay = absf(R.y), az = absf(R.z);
+    V rp;
+    if (ax <= ay && ax <= az)
+        rp = mk(1.0f, R.y, R.z);
+    else if (ay <= az)
+        rp = mk(R.x, 1.0f, R.z);
+    else
+        rp = mk(R.x, R.y, 1.0f);
+    V u = normalize(cross(R, rp));
+    V v = cross(R, u);
+    float xi1 = r_xi1 - 0.5f, xi2 = r_xi2 - 0.5f;
+    V off = scl(add(scl(u, xi1), scl(v, xi2)), roughness);
+    R = add(R, off);
+}
+__device__ V reflect_dir(V N, V I, float roughness, uint32_t key) {
+    float d = dot(I, N);
+    V R = add(I, scl(N, d * -2.0f));
+    if (roughness > 0.0f) add_roughness(R, roughness, rnd(key, DIM_REFLECT_XI1), rnd(key, DIM_REFLECT_XI2));
+    return normalize(R);
+}
+__device__ bool refract_dir(V N, V I, float n1, float n2, float roughness, uint32_t key, V &T) {
+    float cosi = -dot(I, N);
+    float eta = rt_div(n1, n2);
+    float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+    if (k < 0.0f) return false;
+    T = add(scl(I, eta), scl(N, (eta * cosi - rt_sqrt(k))));
+    if (roughness > 0.0f) add_roughness(T, roughness, rnd(key, DIM_REFRACT_XI1), rnd(key, DIM_REFRACT_XI2));
+    T = normalize(T);
+    return true;
+}
+// exact conductor Fresnel reflectance, src/ray_trace.cpp:751-786
+__device__ float conductor_fresnel(float cos_theta, float n, float k) {
+    float c = cos_theta, c2 = c * c, s2 = 1.0f - c2;
+    float n2 = n * n, k2 = k * k, n2_k2 = n2 - k2, n2k2_4 = 4.0f * n2 * k2;
+    float a2_b2 = rt_sqrt((n2_k2 - s2) * (n2_k2 - s2) + n2k2_4);
+    float a2 = 0.5f * (a2_b2 + n2_k2 - s2);
+    float a = rt_sqrt(a2);
+    float b2 = a2_b2 - a2;
+    float b = rt_sqrt(b2);
+    float rs_num = a2_b2 + c2 - (2.0f * a * c);
+    float rs_den = a2_b2 + c2 + (2.0f * a * c);
+    float rs = (rs_den == 0.0f) ? 1.0f : rt_div(rs_num, rs_den);
+    float ac = a * c, bc = b * c;
+    float t1n = ac - s2, t1d = ac + s2;
+    float rp_num = (t1n * t1n) + (bc * bc);
+    float rp_den = (t1d * t1d) + (bc * bc);
+    float rp = (rp_den == 0.0f) ? 1.0f : rs * rt_div(rp_num, rp_den);
+    float F = 0.5f * (rs + rp);
+    return F < 0.0f ? 0.0f : (F > 1.0f ? 1.0f : F);
+}
+
+// ---- normal / bump mapping (src/ray_trace.cpp:494-644) ------------------------------------------------
+__device__ void apply_normal_map(const DevScene &S, const Surface &s, V p, V &normal, Counters &c) {
+    for (int k = 0; k < s.tcount; ++k) {
+        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
+        if (tex.decal_mode != RT_DECAL_REPLACE_NORMAL) continue;
+        float u, v;
+        uv_of(S, s, p, u, v);
+        V raw = mk(0.5f, 0.5f, 1.0f);
+        tex_sample(S, tex, u, v, p, raw, c);
+        V ts = sub(scl(raw, 2.0f), mk(1.0f, 1.0f, 1.0f));
+        V T = tangent_of(S, s, p);
+        float ndott = dot(normal, T);
+        T = normalize(sub(T, scl(normal, ndott)));
+        V B = cross(normal, T);
+        V nn = add(add(scl(T, ts.x), scl(B, ts.y)), scl(normal, ts.z));
+        normal = normalize(nn);
+        return;
+    }
+}
+__device__ void apply_bump_map(const DevScene &S, const Surface &s, V p, V &normal, Counters &c) {
+    for (int k = 0; k < s.tcount; ++k) {
+        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
+        if (tex.decal_mode != RT_DECAL_BUMP_NORMAL) continue;
+        if (tex.image >= 0) {
+            const rt_image &im = S.images[tex.image];
+            float u, v;
+            uv_of(S, s, p, u, v);
+            float du = rt_div(1.0f, (float)im.width), dv = rt_div(1.0f, (float)im.height);
+            V hc = mk(0, 0, 0), hu = mk(0, 0, 0), hv = mk(0, 0, 0);
+            tex_sample(S, tex, u, v, p, hc, c);
+            tex_sample(S, tex, u + du, v, p, hu, c);
+            tex_sample(S, tex, u, v + dv, p, hv, c);
+            float dh_du = (hu.x - hc.x) * tex.bump_factor;
+            float dh_dv = (hv.x - hc.x) * tex.bump_factor;
+            V T = tangent_of(S, s, p);
+            float ndott = dot(normal, T);
+            T = normalize(sub(T, scl(normal, ndott)));
+            V B = cross(normal, T);
+            V nn = sub(sub(normal, scl(T, dh_du)), scl(B, dh_dv));
+            normal = normalize(nn);
+        } else {
+            const float eps = 0.01f;
+            const float inv_eps = 1.0f / eps;
+            V hc, hx, hy, hz;
+            tex_sample(S, tex, 0, 0, p, hc, c);
+            tex_sample(S, tex, 0, 0, add(p, mk(eps, 0, 0)), hx, c);
+            tex_sample(S, tex, 0, 0, add(p, mk(0, eps, 0)), hy, c);
+            tex_sample(S, tex, 0, 0, add(p, mk(0, 0, eps)), hz, c);
+            V g = mk((hx.x - hc.x) * inv_eps, (hy.x - hc.x) * inv_eps, (hz.x - hc.x) * inv_eps);
+            float gdn = dot(g, normal);
+            V surf = sub(g, scl(normal, gdn));
+            normal = normalize(sub(normal, scl(surf, tex.bump_factor)));
+        }
+        return;
+    }
+}
+
+// resolve_textures, src/ray_trace.cpp:107-152.  kd_rr: the diffuse reflectance Russian roulette reads
+// (the reference's blend_kd update does not reach the scalar copies that roulette looks at).
+__device__ void resolve_textures(const DevScene &S, const Surface &s, V p, const rt_material &m, V &kd, V &ks, V &kd_rr,
+                                 bool &replace_all, V &replace_color, Counters &c) {
+    kd = mk(m.diffuse);
+    ks = mk(m.specular);
+    kd_rr = kd;
+    replace_all = false;
+    for (int k = 0; k < s.tcount; ++k) {
+        const rt_texture &tex = S.textures[S.texture_refs[s.toff + k]];
+        float u, v;
+        if (tex.decal_mode == RT_DECAL_REPLACE_KD) {
+            uv_of(S, s, p, u, v);
+            tex_sample(S, tex, u, v, p, kd, c);
+            kd_rr = kd;
+        } else if (tex.decal_mode == RT_DECAL_BLEND_KD) {
+            uv_of(S, s, p, u, v);
+            V tmp = mk(0, 0, 0);
+            tex_sample(S, tex, u, v, p, tmp, c);
+            kd = scl(add(mk(m.diffuse), tmp), 0.5f);
+        } else if (tex.decal_mode == RT_DECAL_REPLACE_KS) {
+            uv_of(S, s, p, u, v);
+            tex_sample(S, tex, u, v, p, ks, c);
+        } else if (tex.decal_mode == RT_DECAL_REPLACE_ALL) {
+            uv_of(S, s, p, u, v);
+            replace_color = mk(0, 0, 0);
+            tex_sample(S, tex, u, v, p, replace_color, c);
+            replace_all = true;
+            return;
+        }
+    }
+}
+
+// ---- lights (Light::get_sample, src/lights.cpp) ------------------------------------------------------
+__device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal, float ru, float rv, V &radiance, V &ldir,
+                             float &dist, Counters &c) {
+    const float pi = 3.14159265359f;
+    radiance = mk(0, 0, 0);
+    switch (L.type) {
+        case RT_LIGHT_POINT: {
+            V du = sub(mk(L.position), p);
+            float d2 = dot(du, du);
+            dist = rt_sqrt(d2);
+            if (d2 < 1e-6f) {
+                ldir = du;
+                return;
+            }
+            ldir = scl(du, rt_div(1.0f, dist));
+            radiance = scl(mk(L.color), rt_div(1.0f, d2));
+            return;
+        }
+        case RT_LIGHT_AREA: {
+            float uo = (ru - 0.5f) * L.size, vo = (rv - 0.5f) * L.size;
+            V sp = add(add(mk(L.position), scl(mk(L.u), uo)), scl(mk(L.v), vo));
+            V du = sub(sp, p);
+            float d2 = dot(du, du);
+            dist = rt_sqrt(d2);
+            ldir = scl(du, rt_div(1.0f, dist));
+            float cos_l = dot(mk(L.normal), scl(ldir, -1.0f));
+            if (cos_l <= 0.0f) return;
+            float area = L.size * L.size;
+            radiance = scl(mk(L.color), rt_div(area * cos_l, d2));
+            return;
+        }
+        case RT_LIGHT_DIRECTIONAL: {
+            dist = 3.402823466e+38f;
+            ldir = scl(mk(L.direction), -1.0f);
+            radiance = mk(L.color);
+            return;
+        }
+        case RT_LIGHT_SPOT: {
+            V du = sub(mk(L.position), p);
+            float d2 = dot(du, du);
+            dist = rt_sqrt(d2);
+            if (d2 < 1e-6f) {
+                ldir = du;
+                return;
+            }
+            ldir = scl(du, rt_div(1.0f, dist));
+            float cos_alpha = dot(scl(ldir, -1.0f), mk(L.direction));
+            float spot = 0.0f;
+            if (cos_alpha > L.cos_falloff) {
+                spot = 1.0f;
+            } else if (cos_alpha > L.cos_coverage) {
+                float ratio = rt_div(cos_alpha - L.cos_coverage, L.cos_falloff - L.cos_coverage);
+                spot = ratio * ratio * ratio * ratio;
+            }
+            radiance = scl(mk(L.color), rt_div(spot, d2));
+            return;
+        }
+        case RT_LIGHT_ENV: {
+            dist = 3.402823466e+38f;
+            float phi = 2.0f * pi * ru, cos_t, sin_t, pdf;
+            if (L.cosine_sampling) {
+                cos_t = rt_sqrt(rv);
+                sin_t = rt_sqrt(1.0f - cos_t * cos_t);
+                pdf = rt_div(cos_t, pi);
+            } else {
+                cos_t = rv;
+                sin_t = rt_sqrt(1.0f - cos_t * cos_t);
+                pdf = 1.0f / (2.0f * pi);
+            }
+            float lx = sin_t * rt_cos(phi), ly = sin_t * rt_sin(phi), lz = cos_t;
+            V w = normal;
+            V up = absf(w.y) < 0.9f ? mk(0, 1, 0) : mk(0, 0, 1);
+            V u = normalize(cross(up, w));
+            V vb = normalize(cross(w, u));
+            ldir = normalize(add(add(scl(u, lx), scl(vb, ly)), scl(w, lz)));
+            float uu, vv;
+            if (L.is_probe)
+                probe_uv(ldir, uu, vv);
+            else
+                latlong_uv(ldir, uu, vv);
+            if (L.image >= 0) image_sample(S, S.images[L.image], true, uu, vv, radiance, c);
+            if (pdf < 1e-6f) pdf = 1e-6f;
+            radiance = scl(radiance, rt_div(1.0f, pdf));
+            return;
+        }
+        case RT_LIGHT_TRIANGLE: {
+            float sr = rt_sqrt(ru);
+            float u = 1.0f - sr, v = rv * sr, w = 1.0f - u - v;
+            V sp = add(add(scl(mk(L.v0), w), scl(mk(L.v1), u)), scl(mk(L.v2), v));
+            V du = sub(sp, p);
+            float d2 = dot(du, du);
+            dist = rt_sqrt(d2);
+            ldir = scl(du, rt_div(1.0f, dist));
+            float cos_l = absf(dot(mk(L.normal), scl(ldir, -1.0f)));
+            radiance = scl(mk(L.color), rt_div(L.area * cos_l, d2));
+            return;
+        }
+        case RT_LIGHT_SPHERE: {
+            const rt_sphere &s = S.spheres[L.sphere];
+            float phi = 2.0f * 3.14159265359f * ru;
+            float cos_t = 1.0f - 2.0f * rv;
+            float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
+            V unit = mk(sin_t * rt_cos(phi), sin_t * rt_sin(phi), cos_t);
+            // the reference transforms the scalar copies of the sampled point, which are still zero
+            // (src/lights.cpp:418-422): the position used is model * (0,0,0,1)
+            V sp = xpoint(s.model, mk(0, 0, 0));
+            V nl = normalize(xdir(s.normal, unit));
+            V du = sub(sp, p);
+            float d2 = dot(du, du);
+            dist = rt_sqrt(d2);
+            ldir = scl(du, rt_div(1.0f, dist));
+            float cos_l = dot(nl, scl(ldir, -1.0f));
+            if (cos_l <= 0.0f) return;
+            radiance = scl(mk(L.color), rt_div(L.area * cos_l, d2));
+            return;
+        }
+    }
+    ldir = mk(0, 0, 0);
+    dist = 0.f;
+}
+
+// calculate_color, src/ray_trace.cpp:154-406 (the last-blocker cache :158-159,207-226 is not used).
+// The five BRDFs of calculate_color (src/ray_trace.cpp:246-389): diffuse and specular factors for one light
+// direction, before multiplication by the incident radiance.
+__device__ void brdf_terms(const rt_material &m, V normal, V ldir, V view, V kd, V ks, V &fd, V &fs) {
+    float ndotl = max_std(dot(normal, ldir), 0.0f);
+    V hv = normalize(add(ldir, view));
+    fd = mk(0, 0, 0);
+    fs = mk(0, 0, 0);
+    const float p_exp = m.phong_exponent;
+    const float PI = 3.14159265359f;
+    switch (m.brdf) {
+        case RT_BRDF_ORIGINAL_BLINN_PHONG: {
+            fd = scl(kd, ndotl);
+            float ndoth = max_std(dot(normal, hv), 0.0f);
+            fs = scl(ks, rt_pow(ndoth, p_exp));
+            break;
+        }
+        case RT_BRDF_ORIGINAL_PHONG: {
+            fd = scl(kd, ndotl);
+            V R = reflect_dir(normal, scl(ldir, -1.0f), 0.f, 0);
+            float rdoth = max_std(dot(R, view), 0.0f);
+            fs = scl(ks, rt_pow(rdoth, p_exp));
+            break;
+        }
+        case RT_BRDF_MODIFIED_BLINN_PHONG: {
+            float ndoth = max_std(dot(normal, hv), 0.0f);
+            if (m.normalized) {
+                fd = scl(kd, 1.0f / PI * ndotl);
+                float norm = rt_div(p_exp + 8.0f, 8.0f * PI);
+                fs = scl(ks, norm * rt_pow(ndoth, p_exp) * ndotl);
+            } else {
+                fd = scl(kd, ndotl);
+                fs = scl(ks, rt_pow(ndoth, p_exp) * ndotl);
+            }
+            break;
+        }
+        case RT_BRDF_MODIFIED_PHONG: {
+            V R = reflect_dir(normal, scl(ldir, -1.0f), 0.f, 0);
+            float rdoth = max_std(dot(R, view), 0.0f);
+            if (m.normalized) {
+                fd = scl(kd, 1.0f / PI * ndotl);
+                float norm = rt_div(p_exp + 2.0f, 2.0f * PI);
+                fs = scl(ks, norm * rt_pow(rdoth, p_exp) * ndotl);
+            } else {
+                fd = scl(kd, ndotl);
+                fs = scl(ks, rt_pow(rdoth, p_exp) * ndotl);
+            }
+            break;
+        }
+        case RT_BRDF_TORRANCE_SPARROW: {
+            float ndoth = max_std(dot(normal, hv), 0.0f);
+            float ndotv = max_std(dot(normal, view), 0.0f);
+            float vdoth = max_std(dot(view, hv), 0.0f);
+            float D = rt_div(p_exp + 2.0f, 2.0f * PI) * rt_pow(ndoth, p_exp);
+            float f_term = rt_pow(1.0f - vdoth, 5.0f);
+            V one = mk(1, 1, 1);
+            V F = add(ks, scl(sub(one, ks), f_term));
+            float G = 1.0f;
+            if (vdoth > 1e-6f) {
+                float g1 = rt_div(2.0f * ndoth * ndotv, vdoth);
+                float g2 = rt_div(2.0f * ndoth * ndotl, vdoth);
+                G = min_std(1.0f, min_std(g1, g2));
+            }
+            if (ndotv > 1e-6f) {
+                float denom = 4.0f * ndotv;
+                fs = scl(F, rt_div(D * G, denom));
+            }
+            if (m.kdfresnel)
+                fd = mul(scl(kd, ndotl), sub(one, F));
+            else
+                fd = scl(kd, 1.0f / PI * ndotl);
+            break;
+        }
+    }
+}
+
+// ---- camera (camera::get_samples, src/camera.cpp:117-224) --------------------------------------------
+__device__ void camera_sample(const rt_camera_desc &cam, int i, int j, int s, int grid_n, uint32_t key, V &o, V &dir, float &time) {
+    V pos = mk(cam.position), cu = mk(cam.u), cv = mk(cam.v), cw = mk(cam.w), center = mk(cam.center);
+    if (cam.num_samples == 1) {
+        float su = cam.near_left + rt_div((cam.near_right - cam.near_left) * (i + 0.5f), (float)cam.resx);
+        float sv = cam.near_bottom + rt_div((cam.near_top - cam.near_bottom) * (j + 0.5f), (float)cam.resy);
+        V target = add(add(center, scl(cu, su)), scl(cv, sv));
+        dir = normalize(sub(target, pos));
+        o = pos;
+        time = rnd(key, DIM_CAM_TIME);
+        return;
+    }
+    int sy = s / grid_n, sx = s % grid_n;
+    float r1 = rnd(key, DIM_CAM_R1), r2 = rnd(key, DIM_CAM_R2);
+    float sub_u = rt_div(sx + r1, (float)grid_n);
+    float sub_v = rt_div(sy + r2, (float)grid_n);
+    float su = cam.near_left + rt_div((cam.near_right - cam.near_left) * (i + sub_u), (float)cam.resx);
+    float sv = cam.near_bottom + rt_div((cam.near_top - cam.near_bottom) * (j + sub_v), (float)cam.resy);
+    V target = add(add(center, scl(cu, su)), scl(cv, sv));
+    dir = normalize(sub(target, pos));
+    o = pos;
+    if (cam.aperture_size > 0.0f && cam.focus_distance > 0.0f) {
+        float cos_theta = -dot(dir, cw);
+        if (absf(cos_theta) < 1e-6f) cos_theta = 1e-6f;
+        float t = rt_div(cam.focus_distance, cos_theta);
+        V focal = add(pos, scl(dir, t));
+        float r3 = rnd(key, DIM_CAM_R3), r4 = rnd(key, DIM_CAM_R4);
+        float lens_x = (r3 - 0.5f) * cam.aperture_size;
+        float lens_y = (r4 - 0.5f) * cam.aperture_size;
+        V lens = add(scl(cu, lens_x), scl(cv, lens_y));
+        o = add(pos, lens);
+        dir = normalize(sub(focal, o));
+    }
+    time = rnd(key, DIM_CAM_TIME);
+}
+
+// ---- pending rays of one camera sample -----------------------------------------------------------------
+
+}  // namespace rt
