@@ -72,8 +72,16 @@ struct VertexBuf {      // one record per shading point that needs direct lighti
     float4 *n_key;      // shading normal.xyz, bits(key)
     float4 *view_mat;   // unit vector towards the ray origin .xyz, bits(material index)
     float4 *kd_slot;    // diffuse reflectance after textures .xyz, bits(slot)
-    float4 *ks_w;       // specular reflectance after textures .xyz, (unused)
-    float4 *weight;     // path throughput x LDR scale .xyz, (unused)
+    float4 *ks_n;       // specular reflectance after textures .xyz, bits(number of shadow records of this pass)
+    float4 *weight;     // path throughput .xyz, LDR scale (1 or 0.004, src/ray_trace.cpp:402-405)
+    float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it), bits(first shadow record of this pass)
+};
+
+struct ShadowQueue {    // one record per light sample with non-zero incident radiance
+    float4 *o_dist;     // shadow-ray origin.xyz, distance to the light sample
+    float4 *d_time;     // direction.xyz, ray time
+    float4 *fd_vis;     // diffuse term x radiance x 1/samples .xyz, visibility (written by the any-hit kernel)
+    float4 *fs_;        // specular term x radiance x 1/samples .xyz
 };
 
 struct Wavefront {
@@ -81,6 +89,9 @@ struct Wavefront {
     float *hit_t;
     int *hit_prim;
     VertexBuf vtx;
+    ShadowQueue shadow;
+    unsigned *shadow_count;   // [MAX_GENERATIONS + 1], reset before every light pass
+    unsigned shadow_capacity;
     float *accum;             // 3 floats per slot
     unsigned *path_count;     // [MAX_GENERATIONS + 1] entries per generation
     unsigned *vertex_count;   // [MAX_GENERATIONS + 1]
@@ -175,6 +186,7 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
 // ---- closest: bvh::intersect (src/bvh.cpp:383-480) for every path of generation `gen` -------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
+    __shared__ uint2 stack_lds[LDS_STACK * 256];
     unsigned count = W.path_count[gen];
     if (count > W.capacity) count = W.capacity;
     const PathQueue &Q = W.q[gen & 1];
@@ -187,7 +199,8 @@ __global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, i
             W.hit_prim[idx] = -3;
             continue;
         }
-        const Hit h = traverse<false, COUNT>(S, mk(ot.x, ot.y, ot.z), mk(dk.x, dk.y, dk.z), ot.w, ((df >> 16) & 1) != 0, S.ieps, 1e30f, c);
+        const Hit h = traverse<false, COUNT>(S, stack_lds + threadIdx.x, mk(ot.x, ot.y, ot.z), mk(dk.x, dk.y, dk.z), ot.w, ((df >> 16) & 1) != 0,
+                                            S.ieps, 1e30f, c);
         W.hit_t[idx] = h.t;
         W.hit_prim[idx] = h.prim;
     }
@@ -225,7 +238,8 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
         const bool active = idx < count;
         // per-lane outputs of this pass
         bool want_vertex = false;
-        V v_p = mk(0, 0, 0), v_n = mk(0, 0, 0), v_view = mk(0, 0, 0), v_kd = mk(0, 0, 0), v_ks = mk(0, 0, 0), v_w = mk(0, 0, 0);
+        V v_p = mk(0, 0, 0), v_n = mk(0, 0, 0), v_view = mk(0, 0, 0), v_kd = mk(0, 0, 0), v_ks = mk(0, 0, 0), v_w = mk(0, 0, 0), v_amb = mk(0, 0, 0);
+        float v_scale = 1.0f;
         int v_mat = 0;
         int n_children = 0;          // explicit children 0 (reflect) and 1 (refract), or `n_children` diffuse bounces
         bool diffuse = false;
@@ -345,18 +359,16 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     if (replace_all) {
                         accum_add(W.accum, slot, mul(thr, rep));
                     } else {
-                        const float scale = is_hdr ? 1.0f : 0.004f;
-                        accum_add(W.accum, slot, mul(thr, scl(mul(mk(m.ambient), mk(S.ambient)), scale)));
-                        if (S.n_lights > 0) {
-                            want_vertex = true;
-                            v_p = shade_p;
-                            v_n = shade_n;
-                            v_view = normalize(sub(o, shade_p));
-                            v_kd = kd;
-                            v_ks = ks;
-                            v_w = scl(thr, scale);
-                            v_mat = sf.material;
-                        }
+                        want_vertex = true;   // ambient + lights are summed by the gather kernel in calculate_color's order
+                        v_p = shade_p;
+                        v_n = shade_n;
+                        v_view = normalize(sub(o, shade_p));
+                        v_kd = kd;
+                        v_ks = ks;
+                        v_w = thr;
+                        v_scale = is_hdr ? 1.0f : 0.004f;
+                        v_amb = mul(mk(m.ambient), mk(S.ambient));
+                        v_mat = sf.material;
                     }
                 } else {
                     // ---- path_trace ------------------------------------------------------------------------
@@ -442,7 +454,8 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                                         v_view = normalize(sub(o, p));
                                         v_kd = kd;
                                         v_ks = ks;
-                                        v_w = scl(thr, 0.004f);   // path_trace calls calculate_color with is_hdr = false (:1083)
+                                        v_w = thr;
+                                        v_scale = 0.004f;   // path_trace calls calculate_color with is_hdr = false (:1083)
                                         v_mat = sf.material;
                                     }
                                 }
@@ -473,8 +486,9 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
                     W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(v_mat));
                     W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot));
-                    W.vtx.ks_w[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, 0.f);
-                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
+                    W.vtx.ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, 0.f);
+                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, v_scale);
+                    W.vtx.amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
                 }
             }
         }
@@ -510,12 +524,17 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
     flush_counters(c, stats, false);
 }
 
-// ---- direct: the light loop of calculate_color (src/ray_trace.cpp:182-400) -------------------------------------
-// k_pad lanes (a power of two <= 64) share one vertex; lane kl evaluates light samples kl, kl + k_pad, ...
-// `light_of` maps a light-sample number to its light.  The per-vertex sum is a fixed-shape shuffle tree.
-template <bool COUNT>
-__global__ void __launch_bounds__(256) direct_kernel(DevScene S, Wavefront W, int gen, const int *__restrict__ light_of, int k_total, int k_pad,
-                                                      unsigned long long *__restrict__ stats) {
+// ---- direct lighting = the light loop of calculate_color (src/ray_trace.cpp:182-400) in three kernels --------------
+// light_setup   one lane per (vertex, light sample of this pass): Light::get_sample, BRDF terms, and — when the
+//               incident radiance is non-zero — a shadow record, appended with wave ballots.  The k_pad lanes of a
+//               vertex sit in one wave, so its records are contiguous and in light-sample order; the first lane
+//               stores (first record, record count) in the vertex.
+// any_hit       one lane per shadow record: any-hit traversal, visibility = !(hit && t < dist - epsilon)
+// light_gather  one lane per vertex: ambient, then the visible records' diffuse and specular terms added in
+//               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
+// Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
+__global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
+                                                           int k_total, int k_pad, unsigned long long *__restrict__ stats) {
     unsigned nv = W.vertex_count[gen];
     if (nv > W.capacity) nv = W.capacity;
     const unsigned lane = threadIdx.x & 63u;
@@ -523,53 +542,94 @@ __global__ void __launch_bounds__(256) direct_kernel(DevScene S, Wavefront W, in
     const unsigned wave_global = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * 256u) >> 6;
     const unsigned kl = lane & (unsigned)(k_pad - 1);
+    const unsigned k = (unsigned)pass * 64u + kl;
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
     for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
         const unsigned v = vbase + lane / (unsigned)k_pad;
-        V sum = mk(0, 0, 0);
-        int slot = 0;
-        V weight = mk(0, 0, 0);
-        if (v < nv) {
-            const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v], kds = W.vtx.kd_slot[v], ksw = W.vtx.ks_w[v],
-                         ww = W.vtx.weight[v];
-            const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z);
-            const V kd = mk(kds.x, kds.y, kds.z), ks = mk(ksw.x, ksw.y, ksw.z);
+        bool want = false;
+        V so = mk(0, 0, 0), ldir = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
+        float dist = 0.f, time = 0.f;
+        if (v < nv && k < (unsigned)k_total) {
+            const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v];
+            const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z);
             const uint32_t key = __float_as_uint(nk.w);
-            const rt_material &m = S.materials[__float_as_int(vm.w)];
-            slot = __float_as_int(kds.w);
-            weight = mk(ww.x, ww.y, ww.z);
-            const float time = pt.w;
-            for (unsigned k = kl; k < (unsigned)k_total; k += (unsigned)k_pad) {
-                const int li = light_of[k];
-                const rt_light &L = S.lights[li];
-                const float lw = rt_div(1.0f, (float)L.samples);
-                float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
-                V rad, ldir;
-                float dist;
-                light_sample(S, L, p, normal, r1, r2, rad, ldir, dist, c);
-                if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
-                V so = add(p, scl(ldir, seps));
+            time = pt.w;
+            const rt_light &L = S.lights[light_of[k]];
+            const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
+            V rad;
+            light_sample(S, L, p, normal, r1, r2, rad, ldir, dist, c);
+            if (!(rad.x == 0 && rad.y == 0 && rad.z == 0)) {
+                want = true;
                 ++c.shadow;
-                Hit sh = traverse<true, COUNT>(S, so, ldir, time, false, seps, dist, c);
-                if (sh.prim != -1 && sh.t < dist - seps) continue;
-                V fd, fs;
-                brdf_terms(m, normal, ldir, view, kd, ks, fd, fs);
+                so = add(p, scl(ldir, seps));
+                const float4 kds = W.vtx.kd_slot[v], ksn = W.vtx.ks_n[v];
+                const float lw = rt_div(1.0f, (float)L.samples);
+                brdf_terms(S.materials[__float_as_int(vm.w)], normal, ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z), mk(ksn.x, ksn.y, ksn.z), fd, fs);
                 fd = scl(mul(fd, rad), lw);
                 fs = scl(mul(fs, rad), lw);
-                sum = add(sum, fd);
-                sum = add(sum, fs);
             }
         }
-        for (int off = k_pad >> 1; off > 0; off >>= 1) {
-            sum.x += __shfl_xor(sum.x, off, 64);
-            sum.y += __shfl_xor(sum.y, off, 64);
-            sum.z += __shfl_xor(sum.z, off, 64);
+        const unsigned long long mask = __ballot(want);
+        const unsigned ri = wave_append(want, W.shadow_count + gen);
+        const unsigned wave_base = __shfl(ri, mask ? __ffsll((long long)mask) - 1 : 0, 64);   // record index of the wave's first record
+        if (want) {
+            if (ri >= W.shadow_capacity) {
+                *W.overflow = 1u;
+            } else {
+                W.shadow.o_dist[ri] = make_float4(so.x, so.y, so.z, dist);
+                W.shadow.d_time[ri] = make_float4(ldir.x, ldir.y, ldir.z, time);
+                W.shadow.fd_vis[ri] = make_float4(fd.x, fd.y, fd.z, 0.f);
+                W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
+            }
         }
-        if (v < nv && kl == 0) accum_add(W.accum, slot, mul(weight, sum));
+        if (v < nv && kl == 0) {   // first lane of the vertex: where its records start and how many there are
+            const unsigned group_shift = lane;   // kl == 0 => lane is the group's first lane
+            const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_shift;
+            const unsigned n = (unsigned)__popcll(mask & group);
+            const unsigned before = (unsigned)__popcll(mask & ((1ull << group_shift) - 1ull));
+            ((float *)&W.vtx.ks_n[v])[3] = __uint_as_float(n);
+            ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float(mask ? wave_base + before : 0u);
+        }
+    }
+    flush_counters(c, stats, false);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) any_hit_kernel(DevScene S, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
+    __shared__ uint2 stack_lds[LDS_STACK * 256];
+    unsigned n = W.shadow_count[gen];
+    if (n > W.shadow_capacity) n = W.shadow_capacity;
+    Counters c;
+    memset(&c, 0, sizeof c);
+    const float seps = S.seps;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 od = W.shadow.o_dist[i], dt = W.shadow.d_time[i];
+        const Hit sh = traverse<true, COUNT>(S, stack_lds + threadIdx.x, mk(od.x, od.y, od.z), mk(dt.x, dt.y, dt.z), dt.w, false, seps, od.w, c);
+        const bool in_shadow = sh.prim != -1 && sh.t < od.w - seps;   // src/ray_trace.cpp:232-241
+        ((float *)&W.shadow.fd_vis[i])[3] = in_shadow ? 0.f : 1.f;
     }
     flush_counters(c, stats, COUNT);
+}
+
+__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass) {
+    unsigned nv = W.vertex_count[gen];
+    if (nv > W.capacity) nv = W.capacity;
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nv; v += gridDim.x * 256u) {
+        const float4 ksn = W.vtx.ks_n[v], w = W.vtx.weight[v], af = W.vtx.amb_first[v];
+        const unsigned n = __float_as_uint(ksn.w), first = __float_as_uint(af.w);
+        V color = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
+        for (unsigned r = first; r < first + n && r < W.shadow_capacity; ++r) {
+            const float4 fd = W.shadow.fd_vis[r];
+            if (fd.w == 0.f) continue;
+            const float4 fs = W.shadow.fs_[r];
+            color = add(color, mk(fd.x, fd.y, fd.z));
+            color = add(color, mk(fs.x, fs.y, fs.z));
+        }
+        if (w.w != 1.0f) color = scl(color, w.w);
+        accum_add(W.accum, __float_as_int(W.vtx.kd_slot[v].w), mul(mk(w.x, w.y, w.z), color));
+    }
 }
 
 // ---- resolve: per-sample clamp (src/ray_trace.cpp:1158-1167) and the pixel mean (src/main.cpp:464-483) --------------
@@ -603,6 +663,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(256) primary_kernel(DevScene S, rt_camera_desc cam, int grid_n, int32_t *__restrict__ shape_out,
                                                        int32_t *__restrict__ id_out, float *__restrict__ t_out,
                                                        unsigned long long *__restrict__ stats) {
+    __shared__ uint2 stack_lds[LDS_STACK * 256];
     const int bx = blockIdx.x % ((cam.resx + 15) / 16), by = blockIdx.x / ((cam.resx + 15) / 16);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = bx * 16 + (wave & 1) * 8 + (lane & 7);
@@ -616,7 +677,7 @@ __global__ void __launch_bounds__(256) primary_kernel(DevScene S, rt_camera_desc
         float time;
         camera_sample(cam, i, j, 0, grid_n, skey, o, d, time);
         ++c.primary;
-        const Hit h = traverse<false, COUNT>(S, o, d, 0.0f, false, S.ieps, 1e30f, c);
+        const Hit h = traverse<false, COUNT>(S, stack_lds + threadIdx.x, o, d, 0.0f, false, S.ieps, 1e30f, c);
         int shape = -1, id = -1;
         if (h.prim <= -2) {
             shape = S.n_triangles + S.n_spheres + (-2 - h.prim);
@@ -690,13 +751,16 @@ struct rt_scene {
     bool has_dielectric = false;
 };
 
-// Entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides; ~220 bytes of HBM each).
+constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) + 1;   // path, vertex, shadow counts per generation + overflow flag
+
+// Entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides; ~1.3 KB of HBM each,
+// most of it the 16 shadow records per entry).
 static unsigned wavefront_capacity() {
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
         if (v >= 4096 && v <= (1l << 28)) return (unsigned)v;
     }
-    return 1u << 23;
+    return 1u << 22;
 }
 
 static int ensure_wavefront(rt_scene *s) {
@@ -716,11 +780,18 @@ static int ensure_wavefront(rt_scene *s) {
     if (alloc((void **)&W.hit_t, (size_t)cap * 4) || alloc((void **)&W.hit_prim, (size_t)cap * 4) ||
         alloc((void **)&W.vtx.p_time, (size_t)cap * 16) || alloc((void **)&W.vtx.n_key, (size_t)cap * 16) ||
         alloc((void **)&W.vtx.view_mat, (size_t)cap * 16) || alloc((void **)&W.vtx.kd_slot, (size_t)cap * 16) ||
-        alloc((void **)&W.vtx.ks_w, (size_t)cap * 16) || alloc((void **)&W.vtx.weight, (size_t)cap * 16) ||
-        alloc((void **)&W.accum, (size_t)cap * 12) || alloc((void **)&W.path_count, (2 * (MAX_GENERATIONS + 1) + 1) * sizeof(unsigned)))
+        alloc((void **)&W.vtx.ks_n, (size_t)cap * 16) || alloc((void **)&W.vtx.weight, (size_t)cap * 16) ||
+        alloc((void **)&W.vtx.amb_first, (size_t)cap * 16) || alloc((void **)&W.accum, (size_t)cap * 12) ||
+        alloc((void **)&W.path_count, COUNTER_WORDS * sizeof(unsigned)))
         return 10;
+    const unsigned scap = cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
+    if (alloc((void **)&W.shadow.o_dist, (size_t)scap * 16) || alloc((void **)&W.shadow.d_time, (size_t)scap * 16) ||
+        alloc((void **)&W.shadow.fd_vis, (size_t)scap * 16) || alloc((void **)&W.shadow.fs_, (size_t)scap * 16))
+        return 10;
+    W.shadow_capacity = scap;
     W.vertex_count = W.path_count + (MAX_GENERATIONS + 1);
-    W.overflow = W.path_count + 2 * (MAX_GENERATIONS + 1);
+    W.shadow_count = W.path_count + 2 * (MAX_GENERATIONS + 1);
+    W.overflow = W.path_count + 3 * (MAX_GENERATIONS + 1);
     W.capacity = cap;
     HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
     s->wf = W;
@@ -811,16 +882,46 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     DevScene &D = s->dev;
     auto keep = [&](void *p) { s->allocations.push_back(p); };
 
-    // BVH nodes -> 2 x float4
-    std::vector<float4> nodes((size_t)d->n_bvh_nodes * 2);
-    for (int i = 0; i < d->n_bvh_nodes; ++i) {
-        const rt_bvh_node &n = d->bvh_nodes[i];
-        int meta = n.n_prims > 0 ? n.n_prims : (n.axis << 16);
-        float fo, fm;
-        memcpy(&fo, &n.offset, 4);
-        memcpy(&fm, &meta, 4);
-        nodes[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], fo);
-        nodes[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], fm);
+    // BVH -> interior-node records holding both child boxes (see DevScene); leaves become references
+    std::vector<float4> nodes;
+    int root_ref = 0;
+    {
+        std::vector<int> interior_index(d->n_bvh_nodes, -1);
+        int n_interior = 0;
+        for (int i = 0; i < d->n_bvh_nodes; ++i)
+            if (d->bvh_nodes[i].n_prims == 0) interior_index[i] = n_interior++;
+        bool ok = true;
+        auto ref_of = [&](int i) -> int {
+            const rt_bvh_node &n = d->bvh_nodes[i];
+            if (n.n_prims == 0) return interior_index[i];
+            if (n.n_prims > 128 || n.offset >= (1 << 24)) {
+                ok = false;
+                return 0;
+            }
+            return (int)(0x80000000u | ((unsigned)(n.n_prims - 1) << 24) | (unsigned)n.offset);
+        };
+        nodes.resize((size_t)n_interior * 4);
+        for (int i = 0; i < d->n_bvh_nodes; ++i) {
+            const rt_bvh_node &n = d->bvh_nodes[i];
+            if (n.n_prims != 0) continue;
+            const rt_bvh_node &L = d->bvh_nodes[i + 1], &R = d->bvh_nodes[n.offset];
+            const int lr = ref_of(i + 1), rr = ref_of(n.offset);
+            float fl, fr, fa;
+            memcpy(&fl, &lr, 4);
+            memcpy(&fr, &rr, 4);
+            memcpy(&fa, &n.axis, 4);
+            float4 *o = &nodes[(size_t)interior_index[i] * 4];
+            o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
+            o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
+            o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+            o[3] = make_float4(fl, fr, fa, 0.f);
+        }
+        if (d->n_bvh_nodes > 0) root_ref = ref_of(0);
+        if (!ok) {
+            g_error = "rt_scene_create: a BVH leaf holds more than 128 primitives or the scene has more than 16M leaf entries";
+            delete s;
+            return 3;
+        }
     }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * 3);
@@ -905,6 +1006,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     D.n_planes = d->n_planes;
     D.n_lights = d->n_lights;
     D.n_nodes = d->n_bvh_nodes;
+    D.root_ref = root_ref;
+    if (d->n_bvh_nodes > 0) {
+        memcpy(D.root_min, d->bvh_nodes[0].bmin, sizeof D.root_min);
+        memcpy(D.root_max, d->bvh_nodes[0].bmax, sizeof D.root_max);
+    }
     D.ieps = d->intersection_epsilon;
     D.seps = d->shadow_ray_epsilon;
     D.max_depth = d->max_depth;
@@ -1046,7 +1152,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
-        unsigned long long slots_max = W.capacity / growth;
+        unsigned long long slots_max = std::min<unsigned long long>(W.capacity, W.shadow_capacity / (unsigned)s->k_pad) / growth;
         long long per_tile = 1024ll * n_samples;
         int tiles_now = (int)std::min<long long>(n_owned - tile, std::max<long long>(1, (long long)slots_max / per_tile));
         Batch b;
@@ -1059,7 +1165,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         b.rank = rank;
         b.world = world;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
-        HIP_OK(hipMemsetAsync(W.path_count, 0, (2 * (MAX_GENERATIONS + 1) + 1) * sizeof(unsigned), s->stream));
+        HIP_OK(hipMemsetAsync(W.path_count, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
         const unsigned grid = std::min<unsigned>(grid_cap, (unsigned)((std::min<unsigned long long>(W.capacity, (unsigned long long)slots * growth) + 255) / 256));
         for (int gen = 0; gen < n_gen; ++gen) {
@@ -1071,19 +1177,24 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                 hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
             else
                 hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
-            if (s->k_total > 0) {
+            const int n_pass = (s->k_total + 63) / 64;
+            for (int pass = 0; pass < n_pass; ++pass) {
+                if (pass > 0) HIP_OK(hipMemsetAsync(W.shadow_count + gen, 0, sizeof(unsigned), s->stream));
+                hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, s->stats);
                 if (s->counters)
-                    hipLaunchKernelGGL(direct_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->light_of, s->k_total, s->k_pad, s->stats);
+                    hipLaunchKernelGGL(any_hit_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->stats);
                 else
-                    hipLaunchKernelGGL(direct_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->light_of, s->k_total, s->k_pad, s->stats);
+                    hipLaunchKernelGGL(any_hit_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->stats);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass);
             }
+            if (n_pass == 0 && !pt) hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0);   // ambient only
         }
         hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
         if (*s->host_flags) {   // a queue ran out of room: redo this batch with fewer camera samples in flight
-            if (tiles_now == 1 && (unsigned long long)per_tile * growth > W.capacity) {
+            if (tiles_now == 1 && (unsigned long long)per_tile * growth * (unsigned)s->k_pad > W.shadow_capacity) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
                 return 6;
             }

@@ -10,7 +10,6 @@
 namespace rt {
 
 constexpr int TILE = 32;              // image tile edge used for sharding
-constexpr int TRAVERSAL_STACK = 64;   // src/bvh.cpp:423
 
 enum {
     DIM_REFLECT_XI1 = 0, DIM_REFLECT_XI2 = 1, DIM_REFRACT_XI1 = 2, DIM_REFRACT_XI2 = 3, DIM_RR = 4, DIM_HEMI_1 = 5, DIM_HEMI_2 = 6,
@@ -20,7 +19,9 @@ enum {
 };
 
 // ---- device-resident scene -------------------------------------------------------------------
-// nodes:  2 x float4 per BVH node  {bmin.xyz, bits(offset)} {bmax.xyz, bits(n_prims | axis << 16)}
+// nodes:  4 x float4 per INTERIOR BVH node, holding the boxes of both children:
+//         {Lmin.xyz, Lmax.x} {Lmax.yz, Rmin.xy} {Rmin.z, Rmax.xyz} {bits(Lref), bits(Rref), bits(axis), 0}
+//         child ref >= 0: interior node index; < 0: leaf = 1<<31 | (n_prims - 1) << 24 | first leaf entry
 // prims:  3 x float4 per leaf entry, in leaf order:
 //         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), bits(shape), bits(ref id)}
 //         sphere   {...unused...}                 {0, bits(-1 - sphere), bits(shape), bits(123456)}
@@ -43,6 +44,8 @@ struct DevScene {
     const float *texels_f32;
     const rt_light *lights;
     int n_triangles, n_spheres, n_planes, n_lights, n_nodes;
+    int root_ref;
+    float root_min[3], root_max[3];
     float ieps, seps, max_depth;
     float ambient[3], bg[3];
     int bg_tex, is_probe;
@@ -59,12 +62,41 @@ struct Hit {
 };
 
 // ---- traversal ---------------------------------------------------------------------------------
-// bvh::intersect (src/bvh.cpp:383-480) with intersect_aabb_fast (:348-381): planes first, then an
-// ordered stack traversal (near child first by the sign of the ray direction on the split axis).
-// A hit replaces the current one only if t > eps and t < t_hit, so of equal-distance hits the one
-// found first in this order is kept.
+// bvh::intersect (src/bvh.cpp:383-480) with intersect_aabb_fast (:348-381): planes first, then an ordered
+// stack traversal (near child first by the sign of the ray direction on the split axis).  A hit replaces
+// the current one only if t > eps and t < t_hit, so of equal-distance hits the one found first is kept.
+//
+// Device formulation: an interior node record holds the boxes of BOTH children, so one 64-byte fetch
+// decides both; the far child is pushed together with its entry distance and re-checked against the
+// current closest hit when popped.  That is the reference's "test the node's own box after popping" with
+// the t_hit-independent part of the test done one step earlier: the same nodes pass, in the same order,
+// and the same primitives are tested in the same order.  The first LDS_STACK entries of a lane's stack
+// live in LDS (one 8-byte column per lane), deeper entries spill to private memory.
+constexpr int LDS_STACK = 12;
+constexpr int SPILL_STACK = 52;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
+
+// slab test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance
+__device__ __forceinline__ bool slab(float x0, float y0, float z0, float x1, float y1, float z1, V o, float ix, float iy, float iz,
+                                     bool nx, bool ny, bool nz, float &tmin_out) {
+    float tmin = ((nx ? x1 : x0) - o.x) * ix;
+    float tmax = ((nx ? x0 : x1) - o.x) * ix;
+    const float tymin = ((ny ? y1 : y0) - o.y) * iy;
+    const float tymax = ((ny ? y0 : y1) - o.y) * iy;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    const float tzmin = ((nz ? z1 : z0) - o.z) * iz;
+    const float tzmax = ((nz ? z0 : z1) - o.z) * iz;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    tmin_out = tmin;
+    return tmax > 0.0f;
+}
+
+// `lds` points at this lane's column of a __shared__ uint2 array laid out [LDS_STACK][blockDim.x].
 template <bool ANY, bool COUNT>
-__device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, float eps, float stop_t, Counters &c) {
+__device__ Hit traverse(const DevScene &S, uint2 *lds, V o, V d, float time, bool culling, float eps, float stop_t, Counters &c) {
     Hit h;
     h.t = stop_t;
     h.prim = -1;
@@ -86,32 +118,52 @@ __device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, f
     if (S.n_nodes == 0) return h;
     const float ix = rt_div(1.0f, d.x), iy = rt_div(1.0f, d.y), iz = rt_div(1.0f, d.z);
     const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
-    int stack[TRAVERSAL_STACK];
-    int top = 0;
-    stack[0] = 0;
+    {
+        if (COUNT) ++c.nodes;
+        float tm;
+        if (!slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], o, ix, iy, iz, nx, ny, nz, tm) ||
+            !(tm < h.t))
+            return h;
+    }
+    const int stride = blockDim.x;
+    uint2 spill[SPILL_STACK];
+    int sp = 0;
+    int cur = S.root_ref;
     int cur_inst = -1;   // placement whose object-space ray is cached in oo/dd
     V oo = o, dd = d;
-    while (top >= 0) {
-        const int ni = stack[top--];
-        const float4 n0 = S.nodes[2 * ni], n1 = S.nodes[2 * ni + 1];
-        if (COUNT) ++c.nodes;
-        float tmin = ((nx ? n1.x : n0.x) - o.x) * ix;
-        float tmax = ((nx ? n0.x : n1.x) - o.x) * ix;
-        const float tymin = ((ny ? n1.y : n0.y) - o.y) * iy;
-        const float tymax = ((ny ? n0.y : n1.y) - o.y) * iy;
-        if ((tmin > tymax) || (tymin > tmax)) continue;
-        if (tymin > tmin) tmin = tymin;
-        if (tymax < tmax) tmax = tymax;
-        const float tzmin = ((nz ? n1.z : n0.z) - o.z) * iz;
-        const float tzmax = ((nz ? n0.z : n1.z) - o.z) * iz;
-        if ((tmin > tzmax) || (tzmin > tmax)) continue;
-        if (tzmin > tmin) tmin = tzmin;
-        if (tzmax < tmax) tmax = tzmax;
-        if (!((tmin < h.t) && (tmax > 0.0f))) continue;
-        const int offset = __float_as_int(n0.w);
-        const int meta = __float_as_int(n1.w);
-        const int nprims = meta & 0xffff;
-        if (nprims > 0) {
+    for (;;) {
+        if (cur >= 0) {
+            const float4 n0 = S.nodes[4 * cur], n1 = S.nodes[4 * cur + 1], n2 = S.nodes[4 * cur + 2], n3 = S.nodes[4 * cur + 3];
+            float tl, tr;
+            bool pl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, ix, iy, iz, nx, ny, nz, tl);
+            bool pr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, ix, iy, iz, nx, ny, nz, tr);
+            pl = pl && (tl < h.t);
+            pr = pr && (tr < h.t);
+            const int axis = __float_as_int(n3.z);
+            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+            const int near_ref = __float_as_int(neg ? n3.y : n3.x), far_ref = __float_as_int(neg ? n3.x : n3.y);
+            const bool pn = neg ? pr : pl, pf = neg ? pl : pr;
+            const float tf = neg ? tl : tr;
+            if (COUNT) ++c.nodes;   // the near child is popped (and its box tested) right after the push
+            if (pn) {
+                if (pf || COUNT) {   // with counters on, failing far children are kept so that their later pop is counted
+                    const uint2 e = make_uint2((unsigned)far_ref, __float_as_uint(pf ? tf : __int_as_float(0x7f800000)));
+                    if (sp < LDS_STACK)
+                        lds[sp * stride] = e;
+                    else if (sp < LDS_STACK + SPILL_STACK)
+                        spill[sp - LDS_STACK] = e;
+                    ++sp;   // deeper than 64 would have overrun the reference's own stack; such entries are dropped
+                }
+                cur = near_ref;
+                continue;
+            }
+            if (COUNT) ++c.nodes;   // near failed: the far child is popped next
+            if (pf) {
+                cur = far_ref;
+                continue;
+            }
+        } else {
+            const int offset = cur & 0xffffff, nprims = ((cur >> 24) & 0x7f) + 1;
             for (int i = 0; i < nprims; ++i) {
                 const int k = offset + i;
                 const float4 p2 = S.prims[3 * k + 2];
@@ -162,15 +214,15 @@ __device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, f
                     if (!(tc > eps)) continue;
                 } else {   // sphere::intersect, src/shapes.cpp:407-447
                     if (COUNT) ++c.sph;
-                    const rt_sphere &sp = S.spheres[-1 - inst];
-                    const V so = xpoint(sp.inv_model, o);
-                    const V sd = xdir(sp.inv_model, d);
-                    const V oc = sub(so, mk(sp.center));
+                    const rt_sphere &sp_ = S.spheres[-1 - inst];
+                    const V so = xpoint(sp_.inv_model, o);
+                    const V sd = xdir(sp_.inv_model, d);
+                    const V oc = sub(so, mk(sp_.center));
                     const float a = dot(sd, sd);
                     float b = dot(oc, sd);
                     b *= 2.0f;
                     float cc = dot(oc, oc);
-                    cc -= (sp.radius * sp.radius);
+                    cc -= (sp_.radius * sp_.radius);
                     const float disc = b * b - 4 * a * cc;
                     if (disc < 0.0f) continue;
                     const float sq = rt_sqrt(disc);
@@ -189,16 +241,20 @@ __device__ Hit traverse(const DevScene &S, V o, V d, float time, bool culling, f
                     if (ANY) return h;
                 }
             }
-        } else {
-            const int axis = meta >> 16;
-            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            const int near_i = neg ? offset : ni + 1;
-            const int far_i = neg ? ni + 1 : offset;
-            stack[++top] = far_i;
-            stack[++top] = near_i;
+        }
+        // pop: skip entries whose box no longer starts before the closest hit
+        for (;;) {
+            if (sp == 0) return h;
+            --sp;
+            if (sp >= LDS_STACK + SPILL_STACK) continue;
+            const uint2 e = sp < LDS_STACK ? lds[sp * stride] : spill[sp - LDS_STACK];
+            if (COUNT) ++c.nodes;
+            if (__uint_as_float(e.y) < h.t) {
+                cur = (int)e.x;
+                break;
+            }
         }
     }
-    return h;
 }
 
 // ---- hit decoding -----------------------------------------------------------------------------
