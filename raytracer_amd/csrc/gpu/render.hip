@@ -90,14 +90,24 @@ struct Wavefront {
     int *hit_prim;
     VertexBuf vtx;
     ShadowQueue shadow;
-    unsigned *shadow_count;   // [MAX_GENERATIONS + 1], reset before every light pass
-    unsigned shadow_capacity;
+    unsigned shadow_shard_entries;   // shadow records per shard
     float *accum;             // 3 floats per slot
-    unsigned *path_count;     // [MAX_GENERATIONS + 1] entries per generation
-    unsigned *vertex_count;   // [MAX_GENERATIONS + 1]
+    unsigned *counters;       // [3 kinds][MAX_GENERATIONS + 1][N_SHARDS] entry counts, one 128-byte line each
     unsigned *overflow;       // set when a queue ran out of room
-    unsigned capacity;        // entries per queue / vertex buffer
+    unsigned shard_entries;   // path / vertex entries per shard
+    unsigned capacity;        // N_SHARDS * shard_entries = slots of the accumulator
 };
+
+// Every queue is split into N_SHARDS regions with their own append counters: a producer workgroup appends to
+// shard (blockIdx.x % N_SHARDS), a consumer workgroup walks the entries of shard (blockIdx.x % N_SHARDS) together
+// with the other gridDim.x / N_SHARDS workgroups of that shard.  One counter for a whole queue would serialise
+// millions of wave-level atomics on a single address.
+constexpr int N_SHARDS = 64;
+constexpr int COUNTER_STRIDE = 32;   // in 4-byte words
+enum { Q_PATH = 0, Q_VERTEX = 1, Q_SHADOW = 2 };
+__device__ __forceinline__ unsigned *counter_of(const Wavefront &W, int kind, int gen, int shard) {
+    return W.counters + ((size_t)(kind * (MAX_GENERATIONS + 1) + gen) * N_SHARDS + shard) * COUNTER_STRIDE;
+}
 
 struct Batch {
     int tile_first, tile_count;   // range in this rank's list of owned tiles
@@ -166,7 +176,13 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
         W.accum[3 * (size_t)g + 1] = 0.f;
         W.accum[3 * (size_t)g + 2] = 0.f;
     }
-    const unsigned idx = wave_append(valid, W.path_count);
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned local = wave_append(valid, counter_of(W, Q_PATH, 0, shard));
+    const unsigned idx = shard * W.shard_entries + local;
+    if (valid && local >= W.shard_entries) {
+        *W.overflow = 1u;
+        valid = false;
+    }
     if (valid) {
         const uint32_t pixel_index = (uint32_t)j * (uint32_t)cam.resx + (uint32_t)i;
         const uint32_t skey = sample_key(cam.seed, pixel_index, (uint32_t)s);
@@ -187,12 +203,15 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
 template <bool COUNT>
 __global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
-    unsigned count = W.path_count[gen];
-    if (count > W.capacity) count = W.capacity;
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shard_base = shard * W.shard_entries;
+    unsigned count = *counter_of(W, Q_PATH, gen, shard);
+    if (count > W.shard_entries) count = W.shard_entries;
     const PathQueue &Q = W.q[gen & 1];
     Counters c;
     memset(&c, 0, sizeof c);
-    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < count; idx += gridDim.x * 256u) {
+    for (unsigned li = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; li < count; li += (gridDim.x / N_SHARDS) * 256u) {
+        const unsigned idx = shard_base + li;
         const float4 ot = Q.o_time[idx], dk = Q.d_key[idx];
         const int df = Q.depth_flags[idx];
         if (whitted && (float)(df & 0xffff) >= S.max_depth) {   // depth limit: no traversal, background (src/ray_trace.cpp:649-679)
@@ -207,12 +226,13 @@ __global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, i
     flush_counters(c, stats, COUNT);
 }
 
-__device__ __forceinline__ void put_path(const Wavefront &W, int gen, unsigned idx, V o, V d, float time, V thr, uint32_t key, int slot,
-                                         int depth_flags) {
-    if (idx >= W.capacity) {
+__device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard, unsigned local, V o, V d, float time, V thr, uint32_t key,
+                                         int slot, int depth_flags) {
+    if (local >= W.shard_entries) {
         *W.overflow = 1u;
         return;
     }
+    const unsigned idx = shard * W.shard_entries + local;
     const PathQueue &Q = W.q[gen & 1];
     Q.o_time[idx] = make_float4(o.x, o.y, o.z, time);
     Q.d_key[idx] = make_float4(d.x, d.y, d.z, __uint_as_float(key));
@@ -224,18 +244,21 @@ __device__ __forceinline__ void put_path(const Wavefront &W, int gen, unsigned i
 // Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
 template <bool PT>
 __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
-    unsigned count = W.path_count[gen];
-    if (count > W.capacity) count = W.capacity;
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shard_base = shard * W.shard_entries;
+    unsigned count = *counter_of(W, Q_PATH, gen, shard);
+    if (count > W.shard_entries) count = W.shard_entries;
     const PathQueue &Q = W.q[gen & 1];
-    unsigned *next_count = W.path_count + gen + 1;
-    unsigned *vcount = W.vertex_count + gen;
+    unsigned *next_count = counter_of(W, Q_PATH, gen + 1, shard);
+    unsigned *vcount = counter_of(W, Q_VERTEX, gen, shard);
     const bool is_hdr = cam.is_hdr != 0;
     Counters c;
     memset(&c, 0, sizeof c);
-    const unsigned stride = gridDim.x * 256u;
-    for (unsigned base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < count; base += stride) {
-        const unsigned idx = base + (threadIdx.x & 63u);
-        const bool active = idx < count;
+    const unsigned stride = (gridDim.x / N_SHARDS) * 256u;
+    for (unsigned base = (blockIdx.x / N_SHARDS) * 256u + (threadIdx.x & ~63u); base < count; base += stride) {
+        const unsigned li = base + (threadIdx.x & 63u);
+        const bool active = li < count;
+        const unsigned idx = shard_base + li;
         // per-lane outputs of this pass
         bool want_vertex = false;
         V v_p = mk(0, 0, 0), v_n = mk(0, 0, 0), v_view = mk(0, 0, 0), v_kd = mk(0, 0, 0), v_ks = mk(0, 0, 0), v_w = mk(0, 0, 0), v_amb = mk(0, 0, 0);
@@ -477,11 +500,12 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
         }
         // ---- append the vertex record ------------------------------------------------------------------------
         {
-            const unsigned vi = wave_append(want_vertex, vcount);
+            const unsigned vl = wave_append(want_vertex, vcount);
             if (want_vertex) {
-                if (vi >= W.capacity) {
+                if (vl >= W.shard_entries) {
                     *W.overflow = 1u;
                 } else {
+                    const unsigned vi = shard_base + vl;
                     W.vtx.p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
                     W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
                     W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(v_mat));
@@ -502,7 +526,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
             if (!want) continue;
             ++c.secondary;
             if (!diffuse) {
-                put_path(W, gen + 1, ci, c_o[r], c_d[r], time, c_thr[r], c_key[r], slot, c_df[r]);
+                put_path(W, gen + 1, shard, ci, c_o[r], c_d[r], time, c_thr[r], c_key[r], slot, c_df[r]);
             } else {
                 const bool cosine = cam.importance_sampling != 0;
                 V wi;
@@ -516,7 +540,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                 if (pdf > 1e-6f) w = scl(scl(b_kd, 1.0f / 3.14159265359f), rt_div(ndotl, pdf));
                 w = scl(w, rt_div(1.0f, (float)n_children));
                 if (b_rr < 1.0f && b_rr > 0.0f) w = scl(w, rt_div(1.0f, b_rr));
-                put_path(W, gen + 1, ci, b_origin, wi, time, mul(b_thr, w), child_key(key, BRANCH_BOUNCE + r), slot,
+                put_path(W, gen + 1, shard, ci, b_origin, wi, time, mul(b_thr, w), child_key(key, BRANCH_BOUNCE + r), slot,
                          (depth + 1) | ((int)culling << 16) | (1 << 17));
             }
         }
@@ -535,23 +559,26 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
 __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
                                                            int k_total, int k_pad, unsigned long long *__restrict__ stats) {
-    unsigned nv = W.vertex_count[gen];
-    if (nv > W.capacity) nv = W.capacity;
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
+    unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
+    if (nv > W.shard_entries) nv = W.shard_entries;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned vpw = 64u / (unsigned)k_pad;   // vertices per wave
-    const unsigned wave_global = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    const unsigned n_waves = (gridDim.x * 256u) >> 6;
+    const unsigned wave_global = ((blockIdx.x / N_SHARDS) * 256u + threadIdx.x) >> 6;   // wave number within the shard
+    const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
     const unsigned kl = lane & (unsigned)(k_pad - 1);
     const unsigned k = (unsigned)pass * 64u + kl;
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
     for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
-        const unsigned v = vbase + lane / (unsigned)k_pad;
+        const unsigned vl = vbase + lane / (unsigned)k_pad;
+        const unsigned v = shard_base + vl;
         bool want = false;
         V so = mk(0, 0, 0), ldir = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
         float dist = 0.f, time = 0.f;
-        if (v < nv && k < (unsigned)k_total) {
+        if (vl < nv && k < (unsigned)k_total) {
             const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v];
             const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z);
             const uint32_t key = __float_as_uint(nk.w);
@@ -572,10 +599,11 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             }
         }
         const unsigned long long mask = __ballot(want);
-        const unsigned ri = wave_append(want, W.shadow_count + gen);
+        const unsigned rl = wave_append(want, counter_of(W, Q_SHADOW, gen, shard));
+        const unsigned ri = shadow_base + rl;
         const unsigned wave_base = __shfl(ri, mask ? __ffsll((long long)mask) - 1 : 0, 64);   // record index of the wave's first record
         if (want) {
-            if (ri >= W.shadow_capacity) {
+            if (rl >= W.shadow_shard_entries) {
                 *W.overflow = 1u;
             } else {
                 W.shadow.o_dist[ri] = make_float4(so.x, so.y, so.z, dist);
@@ -584,7 +612,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
             }
         }
-        if (v < nv && kl == 0) {   // first lane of the vertex: where its records start and how many there are
+        if (vl < nv && kl == 0) {   // first lane of the vertex: where its records start and how many there are
             const unsigned group_shift = lane;   // kl == 0 => lane is the group's first lane
             const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_shift;
             const unsigned n = (unsigned)__popcll(mask & group);
@@ -599,12 +627,15 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) any_hit_kernel(DevScene S, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
-    unsigned n = W.shadow_count[gen];
-    if (n > W.shadow_capacity) n = W.shadow_capacity;
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shadow_base = shard * W.shadow_shard_entries;
+    unsigned n = *counter_of(W, Q_SHADOW, gen, shard);
+    if (n > W.shadow_shard_entries) n = W.shadow_shard_entries;
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    for (unsigned li = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; li < n; li += (gridDim.x / N_SHARDS) * 256u) {
+        const unsigned i = shadow_base + li;
         const float4 od = W.shadow.o_dist[i], dt = W.shadow.d_time[i];
         const Hit sh = traverse<true, COUNT>(S, stack_lds + threadIdx.x, mk(od.x, od.y, od.z), mk(dt.x, dt.y, dt.z), dt.w, false, seps, od.w, c);
         const bool in_shadow = sh.prim != -1 && sh.t < od.w - seps;   // src/ray_trace.cpp:232-241
@@ -614,13 +645,16 @@ __global__ void __launch_bounds__(256) any_hit_kernel(DevScene S, Wavefront W, i
 }
 
 __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass) {
-    unsigned nv = W.vertex_count[gen];
-    if (nv > W.capacity) nv = W.capacity;
-    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < nv; v += gridDim.x * 256u) {
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shard_base = shard * W.shard_entries, shadow_end = (shard + 1) * W.shadow_shard_entries;
+    unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
+    if (nv > W.shard_entries) nv = W.shard_entries;
+    for (unsigned vl = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; vl < nv; vl += (gridDim.x / N_SHARDS) * 256u) {
+        const unsigned v = shard_base + vl;
         const float4 ksn = W.vtx.ks_n[v], w = W.vtx.weight[v], af = W.vtx.amb_first[v];
         const unsigned n = __float_as_uint(ksn.w), first = __float_as_uint(af.w);
         V color = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        for (unsigned r = first; r < first + n && r < W.shadow_capacity; ++r) {
+        for (unsigned r = first; r < first + n && r < shadow_end; ++r) {
             const float4 fd = W.shadow.fd_vis[r];
             if (fd.w == 0.f) continue;
             const float4 fs = W.shadow.fs_[r];
@@ -751,14 +785,14 @@ struct rt_scene {
     bool has_dielectric = false;
 };
 
-constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) + 1;   // path, vertex, shadow counts per generation + overflow flag
+constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
 
 // Entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides; ~1.3 KB of HBM each,
 // most of it the 16 shadow records per entry).
 static unsigned wavefront_capacity() {
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
-        if (v >= 4096 && v <= (1l << 28)) return (unsigned)v;
+        if (v >= 65536 && v <= (1l << 27)) return (unsigned)v / (N_SHARDS * 64) * (N_SHARDS * 64);
     }
     return 1u << 22;
 }
@@ -782,16 +816,15 @@ static int ensure_wavefront(rt_scene *s) {
         alloc((void **)&W.vtx.view_mat, (size_t)cap * 16) || alloc((void **)&W.vtx.kd_slot, (size_t)cap * 16) ||
         alloc((void **)&W.vtx.ks_n, (size_t)cap * 16) || alloc((void **)&W.vtx.weight, (size_t)cap * 16) ||
         alloc((void **)&W.vtx.amb_first, (size_t)cap * 16) || alloc((void **)&W.accum, (size_t)cap * 12) ||
-        alloc((void **)&W.path_count, COUNTER_WORDS * sizeof(unsigned)))
+        alloc((void **)&W.counters, COUNTER_WORDS * sizeof(unsigned)))
         return 10;
     const unsigned scap = cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
     if (alloc((void **)&W.shadow.o_dist, (size_t)scap * 16) || alloc((void **)&W.shadow.d_time, (size_t)scap * 16) ||
         alloc((void **)&W.shadow.fd_vis, (size_t)scap * 16) || alloc((void **)&W.shadow.fs_, (size_t)scap * 16))
         return 10;
-    W.shadow_capacity = scap;
-    W.vertex_count = W.path_count + (MAX_GENERATIONS + 1);
-    W.shadow_count = W.path_count + 2 * (MAX_GENERATIONS + 1);
-    W.overflow = W.path_count + 3 * (MAX_GENERATIONS + 1);
+    W.shadow_shard_entries = scap / N_SHARDS;
+    W.overflow = W.counters + COUNTER_WORDS - 1;
+    W.shard_entries = cap / N_SHARDS;
     W.capacity = cap;
     HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
     s->wf = W;
@@ -1152,7 +1185,9 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
-        unsigned long long slots_max = std::min<unsigned long long>(W.capacity, W.shadow_capacity / (unsigned)s->k_pad) / growth;
+        // shards fill unevenly once paths branch or die: plan for 3/4 of the room
+        unsigned long long slots_max = std::min<unsigned long long>(W.capacity, (unsigned long long)W.shadow_shard_entries * N_SHARDS / (unsigned)s->k_pad) / growth;
+        if (growth > 1 || pt) slots_max = slots_max * 3 / 4;
         long long per_tile = 1024ll * n_samples;
         int tiles_now = (int)std::min<long long>(n_owned - tile, std::max<long long>(1, (long long)slots_max / per_tile));
         Batch b;
@@ -1165,9 +1200,11 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         b.rank = rank;
         b.world = world;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
-        HIP_OK(hipMemsetAsync(W.path_count, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
+        HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
-        const unsigned grid = std::min<unsigned>(grid_cap, (unsigned)((std::min<unsigned long long>(W.capacity, (unsigned long long)slots * growth) + 255) / 256));
+        // consumer grids: a whole number of workgroups per shard
+        const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
+        const unsigned grid = per_shard * N_SHARDS;
         for (int gen = 0; gen < n_gen; ++gen) {
             if (s->counters)
                 hipLaunchKernelGGL(closest_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pt ? 0 : 1, s->stats);
@@ -1179,7 +1216,9 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                 hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
             const int n_pass = (s->k_total + 63) / 64;
             for (int pass = 0; pass < n_pass; ++pass) {
-                if (pass > 0) HIP_OK(hipMemsetAsync(W.shadow_count + gen, 0, sizeof(unsigned), s->stream));
+                if (pass > 0)
+                    HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
+                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
                 hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, s->stats);
                 if (s->counters)
                     hipLaunchKernelGGL(any_hit_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->stats);
@@ -1194,7 +1233,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
         if (*s->host_flags) {   // a queue ran out of room: redo this batch with fewer camera samples in flight
-            if (tiles_now == 1 && (unsigned long long)per_tile * growth * (unsigned)s->k_pad > W.shadow_capacity) {
+            if (tiles_now == 1 && growth > 4096) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
                 return 6;
             }
