@@ -96,6 +96,7 @@ def main():
 
     import raytracer_amd as R
     from raytracer_amd import scenegen
+    from raytracer_amd.sharding import gather_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,9 +121,7 @@ def main():
 
     def step():
         _, st = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
-        if world > 1:
-            # every rank wrote only its own tiles into a zeroed frame: a sum-reduce to rank 0 is the gather
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        gather_frame(fb, world)   # every rank wrote only its own tiles into a zeroed frame
         return st
 
     def sync():

@@ -252,6 +252,12 @@ int rt_render(rt_scene *scene, const rt_camera_desc *cam, float *hdr_out, rt_sta
 int rt_render_shard(rt_scene *scene, const rt_camera_desc *cam, int32_t rank, int32_t world, float *hdr_out,
                     rt_stats *stats);
 
+/* Host-only helper for the gather step: owner_out[ty*tiles_x + tx] = rank that renders tile (tx, ty) when a
+ * resx x resy frame is split over `world` ranks; tiles_x = ceil(resx/32), tiles_y = ceil(resy/32), tile row 0 is
+ * the bottom of the image.  Touches no GPU.  (The reference hands tiles to threads dynamically, src/main.cpp:486-
+ * 512; a static map is what lets every rank know the layout without communication.) */
+int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out);
+
 /* Primary visibility only (bvh::intersect for each pixel's first sample, src/bvh.cpp:383-480):
  * shape index, reference instance id (-1/-1 on a miss) and hit distance (1e30 on a miss). */
 int rt_trace_primary(rt_scene *scene, const rt_camera_desc *cam, int32_t *shape_out, int32_t *id_out, float *t_out,

@@ -69,6 +69,7 @@ def gpu_lib():
                                       C.POINTER(A.Stats)]
         g.rt_trace_primary.argtypes = [C.c_void_p, C.POINTER(A.CameraDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(A.Stats)]
+        g.rt_shard_owner_map.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         g.rt_set_counters.argtypes = [C.c_void_p, C.c_int32]
         g.rt_scene_destroy.argtypes = [C.c_void_p]
         g.rt_last_error.restype = C.c_char_p

@@ -1257,6 +1257,18 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
 
 int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats) { return rt_render_shard(s, cam, 0, 1, hdr_out, stats); }
 
+// Host-only: which rank renders which 32x32 tile.  Must stay the inverse of batch_pixel()'s
+// `tile = owned_index * world + rank`.
+int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out) {
+    if (resx < 1 || resy < 1 || world < 1 || !owner_out) {
+        g_error = "rt_shard_owner_map: bad argument";
+        return 1;
+    }
+    const int tiles_x = (resx + TILE - 1) / TILE, tiles_y = (resy + TILE - 1) / TILE;
+    for (int k = 0; k < tiles_x * tiles_y; ++k) owner_out[k] = k % world;
+    return 0;
+}
+
 int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out, int32_t *id_out, float *t_out, rt_stats *stats) {
     if (!s || !cam || !shape_out || !id_out || !t_out) {
         g_error = "rt_trace_primary: null argument";

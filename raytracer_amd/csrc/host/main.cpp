@@ -95,6 +95,8 @@ static int process_file(const char *filename, int thread_count, int threading_ty
         exit(-1);   // the reference exits on unreadable meshes / missing base meshes (src/parser.cpp:855, src/ply_loader.cpp:74)
     }
     for (auto &w : scene.warnings) log_printf("%s\n", w.c_str());
+    // the reference makes this check per camera, before it spawns its threads (src/main.cpp:542-545)
+    if (!scene.cameras.empty() && (thread_count > 4096 || thread_count < 1)) exit(-2);
     rt_scene_desc desc = scene.desc();
     rt_scene *gpu = nullptr;
     if (rt_scene_create(&desc, &gpu) != 0) {
@@ -109,7 +111,6 @@ static int process_file(const char *filename, int thread_count, int threading_ty
         start = std::chrono::high_resolution_clock::now();
         const int W = cam.desc.resx, H = cam.desc.resy;
         std::vector<float> hdr((size_t)W * H * 3, 0.0f);
-        if (thread_count > 4096 || thread_count < 1) exit(-2);
         rt_stats stats;
         if (rt_render(gpu, &cam.desc, hdr.data(), &stats) != 0) {
             log_printf("rt_render failed: %s\n", rt_last_error());

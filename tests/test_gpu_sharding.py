@@ -1,0 +1,73 @@
+"""GPU: image-space shards reassemble to the single-rank frame byte for byte, and size-independent properties of
+the full-size workloads (the oracle is too slow to check 4K frames pixel by pixel)."""
+import numpy as np
+import pytest
+
+import raytracer_amd as R
+from raytracer_amd import scenegen, sharding
+from golden import scenes as GS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,world", [("pathtrace", 2), ("distributed", 3), ("materials", 8)])
+def test_shards_reassemble_byte_identical(name, world, scene_dir):
+    sc = R.Scene(GS.SCENES[name][0](scene_dir))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    full, st = ren.render(cam)
+    total = np.zeros_like(full)
+    rays = 0
+    for rank in range(world):
+        part = np.zeros_like(full)
+        _, sr = ren.render(cam, out=part, rank=rank, world=world)
+        mask = sharding.pixel_mask(cam.resx, cam.resy, rank, world)
+        assert not part[~mask].any()                      # nothing outside the rank's own tiles
+        total += part
+        rays += sr.total_rays
+    # float atomics into a sample's accumulator may re-associate between runs; a frame is reproducible only to that
+    err = np.abs(total - full) / np.maximum(np.abs(full), 1 / 255)
+    assert err.max() <= 1e-5
+    assert rays == st.total_rays                           # same paths, whoever renders them
+
+
+def test_exact_scene_shards_are_bitwise(scene_dir):
+    """1 spp, point lights: one add per light in a fixed order, so sharded and whole frames are bit-identical."""
+    path = scenegen.write_mesh_scene(scene_dir, n=188, width=480, height=270)
+    sc = R.Scene(path)
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    full, _ = ren.render(cam)
+    total = np.zeros_like(full)
+    for rank in range(2):
+        part = np.zeros_like(full)
+        ren.render(cam, out=part, rank=rank, world=2)
+        total += part
+    assert total.tobytes() == full.tobytes()
+    again, _ = ren.render(cam)
+    assert again.tobytes() == full.tobytes()
+
+
+def test_full_size_path_traced_frame_properties(scene_dir):
+    """1M-triangle scene at 3840x2160 (4 spp to keep the test short; per-sample work is what 256 spp repeats)."""
+    path = scenegen.write_path_traced_scene(scene_dir, name="pt1m_props", n=710, width=3840, height=2160, spp=4, max_depth=4)
+    sc = R.Scene(path)
+    assert sc.desc.n_triangles >= 1_000_000
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    img, st = ren.render(cam)
+    assert st.primary_rays == 3840 * 2160 * 4
+    assert st.secondary_rays <= st.primary_rays * 4 and st.shadow_rays > st.primary_rays
+    assert np.isfinite(img).all() and (img >= 0).all() and img.mean() > 0
+    # primary visibility does not depend on how the frame is batched or which seed drives the bounces
+    s0, i0, t0, _ = ren.trace_primary(sc.camera(0, num_samples=1))
+    s1, i1, t1, _ = ren.trace_primary(sc.camera(0, num_samples=1, seed=7))
+    assert np.array_equal(s0, s1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    assert 0.2 < (t0 < 1e29).mean() <= 1.0
+    # a second render with the same seed: same rays, image equal up to atomic re-association
+    img2, st2 = ren.render(cam)
+    assert st2.total_rays == st.total_rays
+    assert np.abs(img2 - img).max() <= 1e-5 * max(1.0, float(img.max()))
+    # a quarter-resolution render of the same camera sees the same scene: mean radiance agrees to Monte-Carlo noise
+    small, _ = ren.render(sc.camera(0, resx=960, resy=540))
+    assert abs(small.mean() - img.mean()) <= 0.05 * img.mean()
