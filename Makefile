@@ -7,11 +7,11 @@ HIPCC ?= hipcc
 CXX ?= g++
 HOST_SRCS = $(addprefix raytracer_amd/csrc/host/,ingest.cpp ply.cpp bvh_build.cpp image_io.cpp jpeg.cpp tonemap.cpp host_api.cpp)
 HOST_HDRS = $(wildcard raytracer_amd/csrc/host/*.h) include/gpu_render.h include/rt_host.h
-HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -std=c++17 -Iinclude -Iraytracer_amd/csrc/gpu
+HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-vector-combine -fPIC -std=c++17 -Iinclude -Iraytracer_amd/csrc/gpu
 
 all: raytracer_amd/librt_gpu.so raytracer_amd/librt_host.so raytracer oracle
 
-raytracer_amd/librt_gpu.so: raytracer_amd/csrc/gpu/render.hip raytracer_amd/csrc/gpu/rt_math.h include/gpu_render.h
+raytracer_amd/librt_gpu.so: raytracer_amd/csrc/gpu/render.hip $(wildcard raytracer_amd/csrc/gpu/*.h) include/gpu_render.h
 	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
 
 raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)

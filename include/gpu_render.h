@@ -259,7 +259,8 @@ int rt_render_shard(rt_scene *scene, const rt_camera_desc *cam, int32_t rank, in
 int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out);
 
 /* Primary visibility only (bvh::intersect for each pixel's first sample, src/bvh.cpp:383-480):
- * shape index, reference instance id (-1/-1 on a miss) and hit distance (1e30 on a miss). */
+ * shape index, reference instance id (-1/-1 on a miss) and hit distance (1e30 on a miss); moving objects
+ * are taken at time 0. */
 int rt_trace_primary(rt_scene *scene, const rt_camera_desc *cam, int32_t *shape_out, int32_t *id_out, float *t_out,
                      rt_stats *stats);
 

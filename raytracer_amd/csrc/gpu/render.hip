@@ -115,6 +115,7 @@ struct Batch {
     int n_samples, grid_n;
     int tiles_x;
     int rank, world;
+    int still;                    // 1: rays carry time 0 whatever the camera sampled (primary-visibility queries)
 };
 
 __device__ __forceinline__ void batch_pixel(const Batch &b, int pl, int &i, int &j) {
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
         camera_sample(cam, i, j, s, b.grid_n, skey, o, d, time);
         ++c.primary;
         const PathQueue &Q = W.q[0];
-        Q.o_time[idx] = make_float4(o.x, o.y, o.z, time);
+        Q.o_time[idx] = make_float4(o.x, o.y, o.z, b.still ? 0.0f : time);
         Q.d_key[idx] = make_float4(d.x, d.y, d.z, __uint_as_float(child_key(skey, BRANCH_ROOT)));
         Q.thr_slot[idx] = make_float4(1.f, 1.f, 1.f, __uint_as_float(g));
         Q.depth_flags[idx] = 0;
@@ -199,31 +200,136 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
     flush_counters(c, stats, false);
 }
 
-// ---- closest: bvh::intersect (src/bvh.cpp:383-480) for every path of generation `gen` -------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(256) closest_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
+// ---- trace: bvh::intersect (src/bvh.cpp:383-480), closest hit for the paths of generation `gen` (ANY = false) or
+// any hit for its shadow records (ANY = true) -------------------------------------------------------------------
+// Persistent waves: the grid is sized to what the chip holds, and every wave keeps pulling rays from its shard's
+// queue until the queue is empty.  Each lane walks its own ray as a small state machine (see rt_device.h); per
+// iteration the wave votes on what to run:
+//   refill   when at least REFILL_MIN lanes have no ray, they claim the next queue entries with one atomic
+//   pop      lanes whose node is finished take the next one from their stack (or finish the ray)
+//   node     lanes at an interior node test both child boxes -- unless enough lanes wait at a leaf
+//   leaf     lanes at a leaf test one primitive each -- once LEAF_MIN lanes wait, or more lanes wait than walk
+// Incoherent rays leave a wave's lanes at different places in the tree; running the long leaf code for one lane
+// while 63 wait (and the reverse) is what the vote avoids.  Each lane still executes exactly the sequential
+// algorithm for its ray, so results and counters do not depend on the schedule.
+constexpr int REFILL_MIN = 16;
+constexpr int LEAF_MIN = 16;
+
+// A finished ray's record: visibility of the light sample (any hit) or the closest hit.
+template <bool ANY>
+__device__ __forceinline__ void ray_result(const Wavefront &W, unsigned idx, float t, int prim, float dist, float eps) {
+    if (ANY) {
+        const bool in_shadow = prim != -1 && t < dist - eps;   // src/ray_trace.cpp:232-241
+        ((float *)&W.shadow.fd_vis[idx])[3] = in_shadow ? 0.f : 1.f;
+    } else {
+        W.hit_t[idx] = t;
+        W.hit_prim[idx] = prim;
+    }
+}
+
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
+    uint2 *lds = stack_lds + threadIdx.x;
+    uint2 spill[SPILL_STACK];
     const int shard = blockIdx.x % N_SHARDS;
-    const unsigned shard_base = shard * W.shard_entries;
-    unsigned count = *counter_of(W, Q_PATH, gen, shard);
-    if (count > W.shard_entries) count = W.shard_entries;
+    unsigned *ctr = counter_of(W, ANY ? Q_SHADOW : Q_PATH, gen, shard);
+    const unsigned room = ANY ? W.shadow_shard_entries : W.shard_entries;
+    unsigned count = ctr[0];
+    if (count > room) count = room;
+    unsigned *fetch = ctr + 1;   // next unclaimed entry of this shard; shares the append counter's line, zeroed with it
+    const unsigned base_idx = shard * room;
     const PathQueue &Q = W.q[gen & 1];
+    const float eps = ANY ? S.seps : S.ieps;
+    const unsigned lane = threadIdx.x & 63;
     Counters c;
     memset(&c, 0, sizeof c);
-    for (unsigned li = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; li < count; li += (gridDim.x / N_SHARDS) * 256u) {
-        const unsigned idx = shard_base + li;
-        const float4 ot = Q.o_time[idx], dk = Q.d_key[idx];
-        const int df = Q.depth_flags[idx];
-        if (whitted && (float)(df & 0xffff) >= S.max_depth) {   // depth limit: no traversal, background (src/ray_trace.cpp:649-679)
-            W.hit_prim[idx] = -3;
-            continue;
+    RayState r;
+    r.cur = REF_IDLE;
+    r.sp = 0;
+    unsigned idx = 0;
+    float dist = 0.f;   // any hit: distance to the light sample
+    bool exhausted = count == 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(r.cur == REF_IDLE);
+        if (idle) {
+            if (!exhausted) {
+                const int n_idle = __popcll(idle);
+                if (n_idle >= REFILL_MIN) {
+                    const int leader = __ffsll((long long)idle) - 1;
+                    unsigned first = 0;
+                    if ((int)lane == leader) first = atomicAdd(fetch, (unsigned)n_idle);
+                    first = __shfl(first, leader, 64);
+                    if (first + (unsigned)n_idle >= count) exhausted = true;
+                    const unsigned mine = first + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+                    if (r.cur == REF_IDLE && mine < count) {
+                        idx = base_idx + mine;
+                        bool go;
+                        if (ANY) {
+                            const float4 od = W.shadow.o_dist[idx], dt = W.shadow.d_time[idx];
+                            r.ox = od.x, r.oy = od.y, r.oz = od.z;
+                            r.dx = dt.x, r.dy = dt.y, r.dz = dt.z;
+                            r.time = dt.w;
+                            r.culling = false;
+                            dist = od.w;
+                            go = ray_begin<true, COUNT>(S, r, eps, dist, c);
+                        } else {
+                            const float4 ot = Q.o_time[idx], dk = Q.d_key[idx];
+                            const int df = Q.depth_flags[idx];
+                            r.ox = ot.x, r.oy = ot.y, r.oz = ot.z;
+                            r.dx = dk.x, r.dy = dk.y, r.dz = dk.z;
+                            r.time = ot.w;
+                            r.culling = ((df >> 16) & 1) != 0;
+                            if (whitted && (float)(df & 0xffff) >= S.max_depth) {   // depth limit: no traversal, background (src/ray_trace.cpp:649-679)
+                                r.t = 1e30f;
+                                r.prim = -3;
+                                go = false;
+                            } else {
+                                go = ray_begin<false, COUNT>(S, r, eps, 1e30f, c);
+                            }
+                        }
+                        if (!go) {
+                            ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                            r.cur = REF_IDLE;
+                        }
+                    }
+                }
+            } else if (idle == ~0ull) {
+                break;
+            }
         }
-        const Hit h = traverse<false, COUNT>(S, stack_lds + threadIdx.x, mk(ot.x, ot.y, ot.z), mk(dk.x, dk.y, dk.z), ot.w, ((df >> 16) & 1) != 0,
-                                            S.ieps, 1e30f, c);
-        W.hit_t[idx] = h.t;
-        W.hit_prim[idx] = h.prim;
+        if (r.cur == REF_POP) {
+            if (!stack_pop<COUNT>(r, lds, spill, c)) {
+                ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                r.cur = REF_IDLE;
+            }
+        }
+        const unsigned long long at_node = __ballot((unsigned)r.cur < (unsigned)REF_POP);
+        const unsigned long long at_leaf = __ballot(r.cur < 0);
+        const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
+        if (n_node && !(n_leaf >= LEAF_MIN || n_leaf >= n_node)) {
+            if ((unsigned)r.cur < (unsigned)REF_POP) node_step<COUNT>(S, r, lds, spill, c);
+        } else if (n_leaf) {
+            if (r.cur < 0) {
+                const int k = r.cur & 0xffffff;
+                float tc;
+                bool done = false;
+                if (prim_test<COUNT>(S, k, r, eps, tc, c) && tc > eps && tc < r.t) {
+                    r.t = tc;
+                    r.prim = k;
+                    done = ANY;
+                }
+                if (done) {
+                    ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                    r.cur = REF_IDLE;
+                } else {
+                    r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
+                }
+            }
+        }
     }
-    flush_counters(c, stats, COUNT);
+    if (COUNT) flush_counters(c, stats, true);
 }
 
 __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard, unsigned local, V o, V d, float time, V thr, uint32_t key,
@@ -624,26 +730,6 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
     flush_counters(c, stats, false);
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) any_hit_kernel(DevScene S, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
-    __shared__ uint2 stack_lds[LDS_STACK * 256];
-    const int shard = blockIdx.x % N_SHARDS;
-    const unsigned shadow_base = shard * W.shadow_shard_entries;
-    unsigned n = *counter_of(W, Q_SHADOW, gen, shard);
-    if (n > W.shadow_shard_entries) n = W.shadow_shard_entries;
-    Counters c;
-    memset(&c, 0, sizeof c);
-    const float seps = S.seps;
-    for (unsigned li = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; li < n; li += (gridDim.x / N_SHARDS) * 256u) {
-        const unsigned i = shadow_base + li;
-        const float4 od = W.shadow.o_dist[i], dt = W.shadow.d_time[i];
-        const Hit sh = traverse<true, COUNT>(S, stack_lds + threadIdx.x, mk(od.x, od.y, od.z), mk(dt.x, dt.y, dt.z), dt.w, false, seps, od.w, c);
-        const bool in_shadow = sh.prim != -1 && sh.t < od.w - seps;   // src/ray_trace.cpp:232-241
-        ((float *)&W.shadow.fd_vis[i])[3] = in_shadow ? 0.f : 1.f;
-    }
-    flush_counters(c, stats, COUNT);
-}
-
 __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_end = (shard + 1) * W.shadow_shard_entries;
@@ -693,43 +779,31 @@ __global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch 
     dst[2] = rt_div(a2, ns);
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) primary_kernel(DevScene S, rt_camera_desc cam, int grid_n, int32_t *__restrict__ shape_out,
-                                                       int32_t *__restrict__ id_out, float *__restrict__ t_out,
-                                                       unsigned long long *__restrict__ stats) {
-    __shared__ uint2 stack_lds[LDS_STACK * 256];
-    const int bx = blockIdx.x % ((cam.resx + 15) / 16), by = blockIdx.x / ((cam.resx + 15) / 16);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = bx * 16 + (wave & 1) * 8 + (lane & 7);
-    const int j = by * 16 + (wave >> 1) * 8 + (lane >> 3);
-    Counters c;
-    memset(&c, 0, sizeof c);
-    if (i < cam.resx && j < cam.resy) {
+// Primary visibility read-out: the closest-hit records of generation 0, written per pixel.
+__global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int32_t *__restrict__ shape_out,
+                                                           int32_t *__restrict__ id_out, float *__restrict__ t_out) {
+    const int shard = blockIdx.x % N_SHARDS;
+    const unsigned shard_base = shard * W.shard_entries;
+    unsigned count = *counter_of(W, Q_PATH, 0, shard);
+    if (count > W.shard_entries) count = W.shard_entries;
+    for (unsigned li = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; li < count; li += (gridDim.x / N_SHARDS) * 256u) {
+        const unsigned idx = shard_base + li;
+        const unsigned slot = __float_as_uint(W.q[0].thr_slot[idx].w);
+        int i, j;
+        batch_pixel(b, (int)(slot % (unsigned)b.n_pixels), i, j);
         const size_t px = (size_t)j * cam.resx + i;
-        const uint32_t skey = sample_key(cam.seed, (uint32_t)px, 0);
-        V o, d;
-        float time;
-        camera_sample(cam, i, j, 0, grid_n, skey, o, d, time);
-        ++c.primary;
-        const Hit h = traverse<false, COUNT>(S, stack_lds + threadIdx.x, o, d, 0.0f, false, S.ieps, 1e30f, c);
+        const int prim = W.hit_prim[idx];
         int shape = -1, id = -1;
-        if (h.prim <= -2) {
-            shape = S.n_triangles + S.n_spheres + (-2 - h.prim);
-            id = -1;
-        } else if (h.prim >= 0) {
-            const float4 p2 = S.prims[3 * h.prim + 2];
+        if (prim <= -2) {
+            shape = S.n_triangles + S.n_spheres + (-2 - prim);
+        } else if (prim >= 0) {
+            const float4 p2 = S.prims[3 * (size_t)prim + 2];
             shape = __float_as_int(p2.z);
             id = __float_as_int(p2.w);
         }
         shape_out[px] = shape;
         id_out[px] = id;
-        t_out[px] = h.prim == -1 ? 1e30f : h.t;
-    }
-    uint32_t vals[9] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels};
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        uint32_t v = wave_sum(vals[k]);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(stats + k, (unsigned long long)v);
+        t_out[px] = prim == -1 ? 1e30f : W.hit_t[idx];
     }
 }
 
@@ -783,6 +857,7 @@ struct rt_scene {
     int *light_of = nullptr;          // light-sample number -> light index
     int k_total = 0, k_pad = 1;
     bool has_dielectric = false;
+    unsigned trace_blocks[2][2] = {{0, 0}, {0, 0}};   // resident workgroups of trace_kernel<ANY, COUNT>, a multiple of N_SHARDS
 };
 
 constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
@@ -831,6 +906,34 @@ static int ensure_wavefront(rt_scene *s) {
     return 0;
 }
 
+// Launches the persistent trace kernel: as many workgroups as stay resident at once, never more than `grid_limit`
+// (the grid a one-ray-per-lane launch would use; small batches need fewer workgroups than the chip holds).
+static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, int whitted) {
+    const bool count = s->counters;
+    unsigned &blocks = s->trace_blocks[any][count];
+    if (!blocks) {
+        int per_cu = 0, cus = 0;
+        const void *fn = any ? (count ? (const void *)trace_kernel<true, true> : (const void *)trace_kernel<true, false>)
+                             : (count ? (const void *)trace_kernel<false, true> : (const void *)trace_kernel<false, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        blocks = std::max(1u, (unsigned)per_cu * (unsigned)cus / N_SHARDS) * N_SHARDS;
+    }
+    const dim3 grid(std::min(blocks, std::max(grid_limit, (unsigned)N_SHARDS)));
+    if (any) {
+        if (count)
+            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+        else
+            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+    } else {
+        if (count)
+            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+        else
+            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+    }
+}
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_error.c_str(); }
@@ -847,7 +950,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     // operand checks: every index the kernels follow must be in range
     for (int i = 0; i < d->n_bvh_prims; ++i) {
         const rt_bvh_prim &p = d->bvh_prims[i];
-        bool ok = p.shape >= 0 && p.shape < d->n_triangles + d->n_spheres && (p.shape >= d->n_triangles || (p.instance >= 0 && p.instance < d->n_instances));
+        bool ok = p.shape >= 0 && p.shape < d->n_triangles + d->n_spheres &&
+                  (p.shape >= d->n_triangles || (p.instance >= 0 && p.instance < d->n_instances && p.instance < PRIM_XFORM_BIT));
         if (!ok) {
             g_error = "rt_scene_create: BVH primitive out of range";
             return 3;
@@ -942,7 +1046,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             float fl, fr, fa;
             memcpy(&fl, &lr, 4);
             memcpy(&fr, &rr, 4);
-            memcpy(&fa, &n.axis, 4);
+            const int axis_bit = 1 << n.axis;
+            memcpy(&fa, &axis_bit, 4);
             float4 *o = &nodes[(size_t)interior_index[i] * 4];
             o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
             o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
@@ -975,7 +1080,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             }
             prims[3 * i] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
             prims[3 * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
-            prims[3 * i + 2] = make_float4(e2[2], as_float(p.instance), as_float(p.shape), as_float(d->instances[p.instance].ref_id));
+            const rt_instance &in = d->instances[p.instance];
+            const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
+            prims[3 * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), as_float(p.shape), as_float(in.ref_id));
         } else {
             prims[3 * i] = make_float4(0, 0, 0, 0);
             prims[3 * i + 1] = make_float4(0, 0, 0, 0);
@@ -1199,6 +1306,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         b.tiles_x = tiles_x;
         b.rank = rank;
         b.world = world;
+        b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
         HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
@@ -1206,10 +1314,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
         const unsigned grid = per_shard * N_SHARDS;
         for (int gen = 0; gen < n_gen; ++gen) {
-            if (s->counters)
-                hipLaunchKernelGGL(closest_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pt ? 0 : 1, s->stats);
-            else
-                hipLaunchKernelGGL(closest_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pt ? 0 : 1, s->stats);
+            launch_trace(s, false, grid, gen, pt ? 0 : 1);
             if (pt)
                 hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
             else
@@ -1220,10 +1325,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
                 hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, s->stats);
-                if (s->counters)
-                    hipLaunchKernelGGL(any_hit_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->stats);
-                else
-                    hipLaunchKernelGGL(any_hit_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, s->stats);
+                launch_trace(s, true, grid, gen, 0);
                 hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass);
             }
             if (n_pass == 0 && !pt) hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0);   // ambient only
@@ -1277,33 +1379,51 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     int grid_n, n_samples;
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     HIP_OK(hipSetDevice(s->device));
+    if (int rc = ensure_wavefront(s)) return rc;
+    const Wavefront &W = s->wf;
     const size_t n = (size_t)cam->resx * cam->resy;
     int32_t *d_shape = nullptr, *d_id = nullptr;
     float *d_t = nullptr;
+    struct Guard {   // frees the read-out buffers on every return path
+        void **p[3];
+        ~Guard() {
+            for (auto q : p)
+                if (*q) (void)hipFree(*q);
+        }
+    } guard{{(void **)&d_shape, (void **)&d_id, (void **)&d_t}};
     HIP_OK(hipMalloc((void **)&d_shape, n * 4));
     HIP_OK(hipMalloc((void **)&d_id, n * 4));
     HIP_OK(hipMalloc((void **)&d_t, n * 4));
     HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
-    dim3 grid((unsigned)(((cam->resx + 15) / 16) * ((cam->resy + 15) / 16))), block(256);
     HIP_OK(hipEventRecord(s->ev0, s->stream));
-    if (s->counters)
-        hipLaunchKernelGGL(primary_kernel<true>, grid, block, 0, s->stream, s->dev, *cam, grid_n, d_shape, d_id, d_t, s->stats);
-    else
-        hipLaunchKernelGGL(primary_kernel<false>, grid, block, 0, s->stream, s->dev, *cam, grid_n, d_shape, d_id, d_t, s->stats);
-    hipError_t le = hipGetLastError();
+    // the same generate -> trace stages as a render, first sample of every pixel only
+    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
+    const int total_tiles = tiles_x * tiles_y;
+    const int tiles_max = (int)std::max(1u, W.capacity / 1024u);
+    for (int tile = 0; tile < total_tiles; tile += tiles_max) {
+        Batch b;
+        b.tile_first = tile;
+        b.tile_count = std::min(tiles_max, total_tiles - tile);
+        b.n_pixels = b.tile_count * 1024;
+        b.n_samples = 1;
+        b.grid_n = grid_n;
+        b.tiles_x = tiles_x;
+        b.rank = 0;
+        b.world = 1;
+        b.still = 1;
+        const unsigned slots = (unsigned)b.n_pixels;
+        HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
+        hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
+        const unsigned grid = std::min(4096u / N_SHARDS, std::max(1u, (slots / N_SHARDS + 255) / 256)) * N_SHARDS;
+        launch_trace(s, false, grid, 0, 0);
+        hipLaunchKernelGGL(primary_out_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, d_shape, d_id, d_t);
+        HIP_OK(hipGetLastError());
+    }
     HIP_OK(hipEventRecord(s->ev1, s->stream));
-    hipError_t e1 = hipMemcpyAsync(shape_out, d_shape, n * 4, hipMemcpyDeviceToHost, s->stream);
-    hipError_t e2 = hipMemcpyAsync(id_out, d_id, n * 4, hipMemcpyDeviceToHost, s->stream);
-    hipError_t e3 = hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s->stream);
-    hipError_t e4 = hipStreamSynchronize(s->stream);
-    (void)hipFree(d_shape);
-    (void)hipFree(d_id);
-    (void)hipFree(d_t);
-    HIP_OK(le);
-    HIP_OK(e1);
-    HIP_OK(e2);
-    HIP_OK(e3);
-    HIP_OK(e4);
+    HIP_OK(hipMemcpyAsync(shape_out, d_shape, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipMemcpyAsync(id_out, d_id, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
     float kernel_ms = 0.f;
     HIP_OK(hipEventElapsedTime(&kernel_ms, s->ev0, s->ev1));
     read_stats(s, stats, kernel_ms, kernel_ms);

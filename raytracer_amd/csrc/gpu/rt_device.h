@@ -20,7 +20,7 @@ enum {
 
 // ---- device-resident scene -------------------------------------------------------------------
 // nodes:  4 x float4 per INTERIOR BVH node, holding the boxes of both children:
-//         {Lmin.xyz, Lmax.x} {Lmax.yz, Rmin.xy} {Rmin.z, Rmax.xyz} {bits(Lref), bits(Rref), bits(axis), 0}
+//         {Lmin.xyz, Lmax.x} {Lmax.yz, Rmin.xy} {Rmin.z, Rmax.xyz} {bits(Lref), bits(Rref), bits(1 << split axis), 0}
 //         child ref >= 0: interior node index; < 0: leaf = 1<<31 | (n_prims - 1) << 24 | first leaf entry
 // prims:  3 x float4 per leaf entry, in leaf order:
 //         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), bits(shape), bits(ref id)}
@@ -72,189 +72,228 @@ struct Hit {
 // the t_hit-independent part of the test done one step earlier: the same nodes pass, in the same order,
 // and the same primitives are tested in the same order.  The first LDS_STACK entries of a lane's stack
 // live in LDS (one 8-byte column per lane), deeper entries spill to private memory.
+//
+// The traversal is cut into steps (ray set-up, pop, interior-node step, one primitive test) that the trace
+// kernel schedules per wave; a lane's position is its `cur` reference:
+//   0 <= cur < REF_POP   interior node to visit
+//   cur < 0              leaf: 1<<31 | (entries left - 1) << 24 | next leaf entry
+//   REF_POP              take the next node from the stack
+//   REF_IDLE             no ray
 constexpr int LDS_STACK = 12;
 constexpr int SPILL_STACK = 52;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
+constexpr int REF_POP = 0x40000000;
+constexpr int REF_IDLE = 0x40000001;
+constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's placement index: the placement moves or transforms the ray
 
-// slab test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance
-__device__ __forceinline__ bool slab(float x0, float y0, float z0, float x1, float y1, float z1, V o, float ix, float iy, float iz,
-                                     bool nx, bool ny, bool nz, float &tmin_out) {
-    float tmin = ((nx ? x1 : x0) - o.x) * ix;
-    float tmax = ((nx ? x0 : x1) - o.x) * ix;
-    const float tymin = ((ny ? y1 : y0) - o.y) * iy;
-    const float tymax = ((ny ? y0 : y1) - o.y) * iy;
-    if ((tmin > tymax) || (tymin > tmax)) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
-    const float tzmin = ((nz ? z1 : z0) - o.z) * iz;
-    const float tzmax = ((nz ? z0 : z1) - o.z) * iz;
-    if ((tmin > tzmax) || (tzmin > tmax)) return false;
-    if (tzmin > tmin) tmin = tzmin;
-    if (tzmax < tmax) tmax = tzmax;
+// Box test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance.  The
+// reference narrows [t_min, t_max] axis by axis and leaves as soon as the interval is empty; for ordered operands
+// that is "largest entry <= smallest exit", evaluated here without branches.  (The two forms differ only when a
+// product is NaN, 0 x inf: a ray parallel to a box face that starts exactly on it.)
+__device__ __forceinline__ bool slab(float x0, float y0, float z0, float x1, float y1, float z1, float ox, float oy, float oz, float ix,
+                                     float iy, float iz, bool nx, bool ny, bool nz, float &tmin_out) {
+    const float tx0 = ((nx ? x1 : x0) - ox) * ix, tx1 = ((nx ? x0 : x1) - ox) * ix;
+    const float ty0 = ((ny ? y1 : y0) - oy) * iy, ty1 = ((ny ? y0 : y1) - oy) * iy;
+    const float tz0 = ((nz ? z1 : z0) - oz) * iz, tz1 = ((nz ? z0 : z1) - oz) * iz;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(tx0, ty0), tz0);
+    const float tmax = __builtin_fminf(__builtin_fminf(tx1, ty1), tz1);
     tmin_out = tmin;
-    return tmax > 0.0f;
+    return (tmin <= tmax) & (tmax > 0.0f);
 }
 
-// `lds` points at this lane's column of a __shared__ uint2 array laid out [LDS_STACK][blockDim.x].
+// The same test for the two child boxes of a node at once: every subtraction and multiplication is a two-wide packed
+// operation (L, R).  Element for element the arithmetic is that of slab().
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_pair(f2 x0, f2 y0, f2 z0, f2 x1, f2 y1, f2 z1, float ox, float oy, float oz, float ix, float iy,
+                                          float iz, bool nx, bool ny, bool nz, float t_hit, float &tl, float &tr, bool &pl, bool &pr) {
+    const f2 tx0 = ((nx ? x1 : x0) - ox) * ix, tx1 = ((nx ? x0 : x1) - ox) * ix;
+    const f2 ty0 = ((ny ? y1 : y0) - oy) * iy, ty1 = ((ny ? y0 : y1) - oy) * iy;
+    const f2 tz0 = ((nz ? z1 : z0) - oz) * iz, tz1 = ((nz ? z0 : z1) - oz) * iz;
+    tl = __builtin_fmaxf(__builtin_fmaxf(tx0.x, ty0.x), tz0.x);
+    tr = __builtin_fmaxf(__builtin_fmaxf(tx0.y, ty0.y), tz0.y);
+    const float ml = __builtin_fminf(__builtin_fminf(tx1.x, ty1.x), tz1.x);
+    const float mr = __builtin_fminf(__builtin_fminf(tx1.y, ty1.y), tz1.y);
+    pl = (tl <= ml) & (ml > 0.0f) & (tl < t_hit);
+    pr = (tr <= mr) & (mr > 0.0f) & (tr < t_hit);
+}
+
+// What a lane keeps of its ray while it walks the tree.
+struct RayState {
+    float ox, oy, oz, dx, dy, dz;   // origin, direction (scalars: aggregates passed by value end up in private memory)
+    float ix, iy, iz;   // 1 / d
+    float time;
+    float t;            // closest accepted distance so far (starts at the ray's stop distance)
+    int prim;           // its leaf entry; <= -2 plane (-2 - index); -1 none
+    int cur, sp;
+    int sgn;            // bit a set: direction component a is negative
+    bool culling;
+};
+
+// Ray set-up: the plane loop (plane::intersect, src/shapes.cpp:506-527) and the root box.  Returns false when the
+// traversal is already over (any-hit satisfied by a plane, no BVH, or the root box is missed).
 template <bool ANY, bool COUNT>
-__device__ Hit traverse(const DevScene &S, uint2 *lds, V o, V d, float time, bool culling, float eps, float stop_t, Counters &c) {
-    Hit h;
-    h.t = stop_t;
-    h.prim = -1;
-    for (int pi = 0; pi < S.n_planes; ++pi) {   // plane::intersect, src/shapes.cpp:506-527
+__device__ __forceinline__ bool ray_begin(const DevScene &S, RayState &r, float eps, float stop_t, Counters &c) {
+    r.t = stop_t;
+    r.prim = -1;
+    r.sp = 0;
+    for (int pi = 0; pi < S.n_planes; ++pi) {
         if (COUNT) ++c.pln;
         const rt_plane &p = S.planes[pi];
-        V n = mk(p.normal);
-        float denom = dot(n, d);
+        const V n = mk(p.normal);
+        const float denom = dot(n, mk(r.dx, r.dy, r.dz));
         if (absf(denom) < eps) continue;
-        float num = dot(sub(mk(p.point), o), n);
-        float tc = rt_div(num, denom);
+        const float num = dot(sub(mk(p.point), mk(r.ox, r.oy, r.oz)), n);
+        const float tc = rt_div(num, denom);
         if (tc < eps) continue;
-        if (tc > eps && tc < h.t) {
-            h.t = tc;
-            h.prim = -2 - pi;
-            if (ANY) return h;
+        if (tc > eps && tc < r.t) {
+            r.t = tc;
+            r.prim = -2 - pi;
+            if (ANY) return false;
         }
     }
-    if (S.n_nodes == 0) return h;
-    const float ix = rt_div(1.0f, d.x), iy = rt_div(1.0f, d.y), iz = rt_div(1.0f, d.z);
-    const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
-    {
+    if (S.n_nodes == 0) return false;
+    r.ix = rt_div(1.0f, r.dx);
+    r.iy = rt_div(1.0f, r.dy);
+    r.iz = rt_div(1.0f, r.dz);
+    r.sgn = (r.ix < 0 ? 1 : 0) | (r.iy < 0 ? 2 : 0) | (r.iz < 0 ? 4 : 0);
+    if (COUNT) ++c.nodes;
+    float tm;
+    if (!slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0,
+              r.iy < 0, r.iz < 0, tm) ||
+        !(tm < r.t))
+        return false;
+    r.cur = S.root_ref;
+    return true;
+}
+
+constexpr int STACK_STRIDE = 256;   // lanes per workgroup = entries per LDS stack level
+
+__device__ __forceinline__ void stack_push(RayState &r, uint2 *lds, uint2 *spill, uint2 e) {
+    if (r.sp < LDS_STACK)
+        lds[r.sp * STACK_STRIDE] = e;
+    else if (r.sp < LDS_STACK + SPILL_STACK)
+        spill[r.sp - LDS_STACK] = e;
+    ++r.sp;   // deeper than 64 would have overrun the reference's own stack; such entries are dropped
+}
+
+// One interior node: both child boxes, near child next, far child pushed.  `lds` is this lane's column of a
+// __shared__ uint2 array laid out [LDS_STACK][STACK_STRIDE].
+template <bool COUNT>
+__device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, Counters &c) {
+    const float4 *np = S.nodes + 4 * (size_t)r.cur;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
+    float tl, tr;
+    bool pl, pr;
+    slab_pair(f2{n0.x, n1.z}, f2{n0.y, n1.w}, f2{n0.z, n2.x}, f2{n0.w, n2.y}, f2{n1.x, n2.z}, f2{n1.y, n2.w}, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nx, ny, nz,
+              r.t, tl, tr, pl, pr);
+    const bool neg = (r.sgn & __float_as_int(n3.z)) != 0;   // n3.z = 1 << split axis
+    const int near_ref = __float_as_int(neg ? n3.y : n3.x), far_ref = __float_as_int(neg ? n3.x : n3.y);
+    const bool pn = neg ? pr : pl, pf = neg ? pl : pr;
+    const float tf = neg ? tl : tr;
+    if (COUNT) {
+        ++c.nodes;             // the near child is popped (and its box tested) right after the push
+        if (!pn) ++c.nodes;    // near failed: the far child is popped next
+        // failing far children are kept so that their later pop is counted
+        if (pn) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(pf ? tf : __int_as_float(0x7f800000))));
+    } else {
+        if (pn & pf) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(tf)));
+    }
+    r.cur = pn ? near_ref : (pf ? far_ref : REF_POP);
+}
+
+// Pops until an entry whose box still starts before the closest hit; false when the stack is empty.
+template <bool COUNT>
+__device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const uint2 *spill, Counters &c) {
+    while (r.sp > 0) {
+        --r.sp;
+        uint2 e;
+        if (r.sp < LDS_STACK)
+            e = lds[r.sp * STACK_STRIDE];
+        else if (r.sp < LDS_STACK + SPILL_STACK)
+            e = spill[r.sp - LDS_STACK];
+        else
+            continue;
         if (COUNT) ++c.nodes;
-        float tm;
-        if (!slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], o, ix, iy, iz, nx, ny, nz, tm) ||
-            !(tm < h.t))
-            return h;
+        if (__uint_as_float(e.y) < r.t) {
+            r.cur = (int)e.x;
+            return true;
+        }
     }
-    const int stride = blockDim.x;
-    uint2 spill[SPILL_STACK];
-    int sp = 0;
-    int cur = S.root_ref;
-    int cur_inst = -1;   // placement whose object-space ray is cached in oo/dd
-    V oo = o, dd = d;
-    for (;;) {
-        if (cur >= 0) {
-            const float4 n0 = S.nodes[4 * cur], n1 = S.nodes[4 * cur + 1], n2 = S.nodes[4 * cur + 2], n3 = S.nodes[4 * cur + 3];
-            float tl, tr;
-            bool pl = slab(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, ix, iy, iz, nx, ny, nz, tl);
-            bool pr = slab(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, ix, iy, iz, nx, ny, nz, tr);
-            pl = pl && (tl < h.t);
-            pr = pr && (tr < h.t);
-            const int axis = __float_as_int(n3.z);
-            const bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-            const int near_ref = __float_as_int(neg ? n3.y : n3.x), far_ref = __float_as_int(neg ? n3.x : n3.y);
-            const bool pn = neg ? pr : pl, pf = neg ? pl : pr;
-            const float tf = neg ? tl : tr;
-            if (COUNT) ++c.nodes;   // the near child is popped (and its box tested) right after the push
-            if (pn) {
-                if (pf || COUNT) {   // with counters on, failing far children are kept so that their later pop is counted
-                    const uint2 e = make_uint2((unsigned)far_ref, __float_as_uint(pf ? tf : __int_as_float(0x7f800000)));
-                    if (sp < LDS_STACK)
-                        lds[sp * stride] = e;
-                    else if (sp < LDS_STACK + SPILL_STACK)
-                        spill[sp - LDS_STACK] = e;
-                    ++sp;   // deeper than 64 would have overrun the reference's own stack; such entries are dropped
-                }
-                cur = near_ref;
-                continue;
+    return false;
+}
+
+// Leaf entry k against the ray; true with the distance in `tc` when the primitive reports a hit (t > eps).
+template <bool COUNT>
+__device__ __forceinline__ bool prim_test(const DevScene &S, int k, const RayState &r, float eps, float &tc, Counters &c) {
+    const float4 p2 = S.prims[3 * (size_t)k + 2];
+    const int inst = __float_as_int(p2.y);
+    if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
+        if (COUNT) ++c.tri;
+        const float4 p0 = S.prims[3 * (size_t)k], p1 = S.prims[3 * (size_t)k + 1];
+        const V ro = mk(r.ox, r.oy, r.oz), rd = mk(r.dx, r.dy, r.dz);
+        V oo = ro, dd = rd;
+        if (inst & PRIM_XFORM_BIT) {
+            const float4 *ip = S.inst + 4 * (size_t)(inst & ~PRIM_XFORM_BIT);
+            const float4 r3 = ip[3];
+            const int flags = __float_as_int(r3.w);
+            V moved = ro;
+            if (flags & 2) moved = sub(ro, scl(mk(r3.x, r3.y, r3.z), r.time));
+            if (flags & 1) {
+                oo = moved;
+            } else {
+                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                oo = mk((r0.x * moved.x + r0.y * moved.y) + (r0.z * moved.z + r0.w), (r1.x * moved.x + r1.y * moved.y) + (r1.z * moved.z + r1.w),
+                        (r2.x * moved.x + r2.y * moved.y) + (r2.z * moved.z + r2.w));
+                dd = mk((r0.x * rd.x + r0.y * rd.y) + r0.z * rd.z, (r1.x * rd.x + r1.y * rd.y) + r1.z * rd.z,
+                        (r2.x * rd.x + r2.y * rd.y) + r2.z * rd.z);
             }
-            if (COUNT) ++c.nodes;   // near failed: the far child is popped next
-            if (pf) {
-                cur = far_ref;
-                continue;
-            }
+        }
+        const V c1s = mk(p0.x, p0.y, p0.z), e1 = mk(p0.w, p1.x, p1.y), e2 = mk(p1.z, p1.w, p2.x);
+        const V os = scl(oo, 1000.0f);
+        const V hh = cross(dd, e2);
+        const float det = dot(e1, hh);
+        if (r.culling) {
+            if (det < eps) return false;
         } else {
-            const int offset = cur & 0xffffff, nprims = ((cur >> 24) & 0x7f) + 1;
-            for (int i = 0; i < nprims; ++i) {
-                const int k = offset + i;
-                const float4 p2 = S.prims[3 * k + 2];
-                const int inst = __float_as_int(p2.y);
-                float tc;
-                if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
-                    if (COUNT) ++c.tri;
-                    const float4 p0 = S.prims[3 * k], p1 = S.prims[3 * k + 1];
-                    if (inst != cur_inst) {
-                        cur_inst = inst;
-                        const float4 r3 = S.inst[4 * inst + 3];
-                        const int flags = __float_as_int(r3.w);
-                        V moved = o;
-                        if (flags & 2) moved = sub(o, scl(mk(r3.x, r3.y, r3.z), time));
-                        if (flags & 1) {
-                            oo = moved;
-                            dd = d;
-                        } else {
-                            const float4 r0 = S.inst[4 * inst], r1 = S.inst[4 * inst + 1], r2 = S.inst[4 * inst + 2];
-                            oo = mk((r0.x * moved.x + r0.y * moved.y) + (r0.z * moved.z + r0.w),
-                                    (r1.x * moved.x + r1.y * moved.y) + (r1.z * moved.z + r1.w),
-                                    (r2.x * moved.x + r2.y * moved.y) + (r2.z * moved.z + r2.w));
-                            dd = mk((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z,
-                                    (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
-                        }
-                    }
-                    const V c1s = mk(p0.x, p0.y, p0.z), e1 = mk(p0.w, p1.x, p1.y), e2 = mk(p1.z, p1.w, p2.x);
-                    const V os = scl(oo, 1000.0f);
-                    const V hh = cross(dd, e2);
-                    const float det = dot(e1, hh);
-                    if (culling) {
-                        if (det < eps) continue;
-                    } else {
-                        if (absf(det) < eps) continue;
-                    }
-                    const float f = rt_div(1.0f, det);
-                    const V s = sub(os, c1s);
-                    float u = dot(s, hh);
-                    u *= f;
-                    if (u < (0.0f - eps) || u > (1.0f + eps)) continue;
-                    const V q = cross(s, e1);
-                    float v = dot(dd, q);
-                    v *= f;
-                    if (v < (0.0f - eps) || (u + v) > (1.0f + eps)) continue;
-                    tc = dot(e2, q);
-                    tc *= f;
-                    tc *= (1.0f / 1000.0f);
-                    if (!(tc > eps)) continue;
-                } else {   // sphere::intersect, src/shapes.cpp:407-447
-                    if (COUNT) ++c.sph;
-                    const rt_sphere &sp_ = S.spheres[-1 - inst];
-                    const V so = xpoint(sp_.inv_model, o);
-                    const V sd = xdir(sp_.inv_model, d);
-                    const V oc = sub(so, mk(sp_.center));
-                    const float a = dot(sd, sd);
-                    float b = dot(oc, sd);
-                    b *= 2.0f;
-                    float cc = dot(oc, oc);
-                    cc -= (sp_.radius * sp_.radius);
-                    const float disc = b * b - 4 * a * cc;
-                    if (disc < 0.0f) continue;
-                    const float sq = rt_sqrt(disc);
-                    const float inv2a = rt_div(1.0f, 2.0f * a);
-                    const float t1 = (-b - sq) * inv2a, t2 = (-b + sq) * inv2a;
-                    if (t1 > eps)
-                        tc = t1;
-                    else if (t2 > eps)
-                        tc = t2;
-                    else
-                        continue;
-                }
-                if (tc > eps && tc < h.t) {
-                    h.t = tc;
-                    h.prim = k;
-                    if (ANY) return h;
-                }
-            }
+            if (absf(det) < eps) return false;
         }
-        // pop: skip entries whose box no longer starts before the closest hit
-        for (;;) {
-            if (sp == 0) return h;
-            --sp;
-            if (sp >= LDS_STACK + SPILL_STACK) continue;
-            const uint2 e = sp < LDS_STACK ? lds[sp * stride] : spill[sp - LDS_STACK];
-            if (COUNT) ++c.nodes;
-            if (__uint_as_float(e.y) < h.t) {
-                cur = (int)e.x;
-                break;
-            }
-        }
+        const float f = rt_div(1.0f, det);
+        const V s = sub(os, c1s);
+        float u = dot(s, hh);
+        u *= f;
+        if (u < (0.0f - eps) || u > (1.0f + eps)) return false;
+        const V q = cross(s, e1);
+        float v = dot(dd, q);
+        v *= f;
+        if (v < (0.0f - eps) || (u + v) > (1.0f + eps)) return false;
+        tc = dot(e2, q);
+        tc *= f;
+        tc *= (1.0f / 1000.0f);
+        return tc > eps;
     }
+    // sphere::intersect, src/shapes.cpp:407-447
+    if (COUNT) ++c.sph;
+    const rt_sphere &sp_ = S.spheres[-1 - inst];
+    const V so = xpoint(sp_.inv_model, mk(r.ox, r.oy, r.oz));
+    const V sd = xdir(sp_.inv_model, mk(r.dx, r.dy, r.dz));
+    const V oc = sub(so, mk(sp_.center));
+    const float a = dot(sd, sd);
+    float b = dot(oc, sd);
+    b *= 2.0f;
+    float cc = dot(oc, oc);
+    cc -= (sp_.radius * sp_.radius);
+    const float disc = b * b - 4 * a * cc;
+    if (disc < 0.0f) return false;
+    const float sq = rt_sqrt(disc);
+    const float inv2a = rt_div(1.0f, 2.0f * a);
+    const float t1 = (-b - sq) * inv2a, t2 = (-b + sq) * inv2a;
+    if (t1 > eps)
+        tc = t1;
+    else if (t2 > eps)
+        tc = t2;
+    else
+        return false;
+    return true;
 }
 
 // ---- hit decoding -----------------------------------------------------------------------------
@@ -279,8 +318,9 @@ __device__ Surface surface_of(const DevScene &S, const Hit &h) {
         return s;
     }
     const float4 p2 = S.prims[3 * h.prim + 2];
-    const int inst = __float_as_int(p2.y);
+    int inst = __float_as_int(p2.y);
     if (inst >= 0) {
+        inst &= ~PRIM_XFORM_BIT;
         s.kind = 0;
         s.index = __float_as_int(p2.z);
         s.instance = inst;
