@@ -212,8 +212,10 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
 // Incoherent rays leave a wave's lanes at different places in the tree; running the long leaf code for one lane
 // while 63 wait (and the reverse) is what the vote avoids.  Each lane still executes exactly the sequential
 // algorithm for its ray, so results and counters do not depend on the schedule.
-constexpr int REFILL_MIN = 16;
-constexpr int LEAF_MIN = 16;
+struct TraceTuning {
+    int refill_min;   // idle lanes that trigger a refill
+    int leaf_min;     // lanes waiting at a leaf that trigger a leaf step
+};
 
 // A finished ray's record: visibility of the light sample (any hit) or the closest hit.
 template <bool ANY>
@@ -228,7 +230,7 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, unsigned idx, flo
 }
 
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
     uint2 *lds = stack_lds + threadIdx.x;
     uint2 spill[SPILL_STACK];
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         if (idle) {
             if (!exhausted) {
                 const int n_idle = __popcll(idle);
-                if (n_idle >= REFILL_MIN) {
+                if (n_idle >= tune.refill_min) {
                     const int leader = __ffsll((long long)idle) - 1;
                     unsigned first = 0;
                     if ((int)lane == leader) first = atomicAdd(fetch, (unsigned)n_idle);
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
             }
         }
         if (r.cur == REF_POP) {
-            if (!stack_pop<COUNT>(r, lds, spill, c)) {
+            if (!stack_pop<(!ANY || COUNT), COUNT>(r, lds, spill, c)) {
                 ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
                 r.cur = REF_IDLE;
             }
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         const unsigned long long at_node = __ballot((unsigned)r.cur < (unsigned)REF_POP);
         const unsigned long long at_leaf = __ballot(r.cur < 0);
         const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
-        if (n_node && !(n_leaf >= LEAF_MIN || n_leaf >= n_node)) {
+        if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) {
             if ((unsigned)r.cur < (unsigned)REF_POP) node_step<COUNT>(S, r, lds, spill, c);
         } else if (n_leaf) {
             if (r.cur < 0) {
@@ -921,16 +923,22 @@ static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, in
         blocks = std::max(1u, (unsigned)per_cu * (unsigned)cus / N_SHARDS) * N_SHARDS;
     }
     const dim3 grid(std::min(blocks, std::max(grid_limit, (unsigned)N_SHARDS)));
+    static const TraceTuning tune = [] {
+        TraceTuning t{16, 16};
+        if (const char *e = getenv("RT_TRACE_REFILL_MIN")) t.refill_min = std::min(64, std::max(1, atoi(e)));
+        if (const char *e = getenv("RT_TRACE_LEAF_MIN")) t.leaf_min = std::min(64, std::max(1, atoi(e)));
+        return t;
+    }();
     if (any) {
         if (count)
-            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
         else
-            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
     } else {
         if (count)
-            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
         else
-            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, s->stats);
+            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
     }
 }
 

@@ -167,12 +167,19 @@ __device__ __forceinline__ bool ray_begin(const DevScene &S, RayState &r, float 
 
 constexpr int STACK_STRIDE = 256;   // lanes per workgroup = entries per LDS stack level
 
+// The private part of the stack is accessed as volatile words so that its loads and stores stay separate
+// instructions from the LDS ones (merged, both would go through the slow generic address path).
 __device__ __forceinline__ void stack_push(RayState &r, uint2 *lds, uint2 *spill, uint2 e) {
-    if (r.sp < LDS_STACK)
+    if (r.sp < LDS_STACK) {
         lds[r.sp * STACK_STRIDE] = e;
-    else if (r.sp < LDS_STACK + SPILL_STACK)
-        spill[r.sp - LDS_STACK] = e;
-    ++r.sp;   // deeper than 64 would have overrun the reference's own stack; such entries are dropped
+    } else if (r.sp < LDS_STACK + SPILL_STACK) {
+        volatile unsigned *w = (volatile unsigned *)(spill + (r.sp - LDS_STACK));
+        w[0] = e.x;
+        w[1] = e.y;
+    } else {
+        return;   // deeper than 64 would have overrun the reference's own stack; such entries are dropped
+    }
+    ++r.sp;
 }
 
 // One interior node: both child boxes, near child next, far child pushed.  `lds` is this lane's column of a
@@ -184,37 +191,38 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
     const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
     float tl, tr;
     bool pl, pr;
-    slab_pair(f2{n0.x, n1.z}, f2{n0.y, n1.w}, f2{n0.z, n2.x}, f2{n0.w, n2.y}, f2{n1.x, n2.z}, f2{n1.y, n2.w}, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nx, ny, nz,
-              r.t, tl, tr, pl, pr);
+    slab_pair(f2{n0.x, n1.z}, f2{n0.y, n1.w}, f2{n0.z, n2.x}, f2{n0.w, n2.y}, f2{n1.x, n2.z}, f2{n1.y, n2.w}, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nx,
+              ny, nz, r.t, tl, tr, pl, pr);
     const bool neg = (r.sgn & __float_as_int(n3.z)) != 0;   // n3.z = 1 << split axis
     const int near_ref = __float_as_int(neg ? n3.y : n3.x), far_ref = __float_as_int(neg ? n3.x : n3.y);
-    const bool pn = neg ? pr : pl, pf = neg ? pl : pr;
-    const float tf = neg ? tl : tr;
+    const bool pn = (neg & pr) | (!neg & pl), pf = (neg & pl) | (!neg & pr);
     if (COUNT) {
         ++c.nodes;             // the near child is popped (and its box tested) right after the push
         if (!pn) ++c.nodes;    // near failed: the far child is popped next
         // failing far children are kept so that their later pop is counted
-        if (pn) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(pf ? tf : __int_as_float(0x7f800000))));
+        if (pn) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(pf ? (neg ? tl : tr) : __int_as_float(0x7f800000))));
     } else {
-        if (pn & pf) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(tf)));
+        if (pn & pf) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(neg ? tl : tr)));
     }
     r.cur = pn ? near_ref : (pf ? far_ref : REF_POP);
 }
 
-// Pops until an entry whose box still starts before the closest hit; false when the stack is empty.
-template <bool COUNT>
+// Pops until an entry whose box still starts before the closest hit; false when the stack is empty.  With
+// CHECK false (an any-hit ray never shortens, so every pushed entry still qualifies) the first entry is taken.
+template <bool CHECK, bool COUNT>
 __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const uint2 *spill, Counters &c) {
     while (r.sp > 0) {
         --r.sp;
         uint2 e;
-        if (r.sp < LDS_STACK)
+        if (r.sp < LDS_STACK) {
             e = lds[r.sp * STACK_STRIDE];
-        else if (r.sp < LDS_STACK + SPILL_STACK)
-            e = spill[r.sp - LDS_STACK];
-        else
-            continue;
+        } else {
+            const volatile unsigned *w = (const volatile unsigned *)(spill + (r.sp - LDS_STACK));
+            e.x = w[0];
+            e.y = w[1];
+        }
         if (COUNT) ++c.nodes;
-        if (__uint_as_float(e.y) < r.t) {
+        if (!CHECK || __uint_as_float(e.y) < r.t) {
             r.cur = (int)e.x;
             return true;
         }
