@@ -864,19 +864,29 @@ struct rt_scene {
 
 constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
 
-// Entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides; ~1.3 KB of HBM each,
-// most of it the 16 shadow records per entry).
+// Upper bound of entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides).  One
+// entry costs ~1.26 KB of HBM, most of it the 16 shadow records; the default of 64 Mi entries is 85 GB of the
+// 288 GB.  Large batches matter: every kernel of a batch ends with a tail in which the last rays finish on a mostly
+// idle chip, and the fewer batches a frame has, the fewer tails it pays for.
 static unsigned wavefront_capacity() {
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
-        if (v >= 65536 && v <= (1l << 27)) return (unsigned)v / (N_SHARDS * 64) * (N_SHARDS * 64);
+        if (v >= 65536 && v <= (1l << 27)) return (unsigned)v / (N_SHARDS * 256) * (N_SHARDS * 256);
     }
-    return 1u << 22;
+    return 1u << 26;
 }
 
-static int ensure_wavefront(rt_scene *s) {
-    if (s->wf.capacity) return 0;
-    const unsigned cap = wavefront_capacity();
+// Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries; grows, never shrinks.
+static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
+    // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
+    const unsigned long long unit = N_SHARDS * 256;
+    wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
+    const unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity());
+    if (s->wf.capacity >= cap) return 0;
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (void *p : s->wf_allocations) (void)hipFree(p);
+    s->wf_allocations.clear();
+    s->wf = Wavefront{};
     Wavefront W{};
     auto alloc = [&](void **p, size_t bytes) -> int {
         HIP_OK(hipMalloc(p, bytes));
@@ -895,15 +905,15 @@ static int ensure_wavefront(rt_scene *s) {
         alloc((void **)&W.vtx.amb_first, (size_t)cap * 16) || alloc((void **)&W.accum, (size_t)cap * 12) ||
         alloc((void **)&W.counters, COUNTER_WORDS * sizeof(unsigned)))
         return 10;
-    const unsigned scap = cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
-    if (alloc((void **)&W.shadow.o_dist, (size_t)scap * 16) || alloc((void **)&W.shadow.d_time, (size_t)scap * 16) ||
-        alloc((void **)&W.shadow.fd_vis, (size_t)scap * 16) || alloc((void **)&W.shadow.fs_, (size_t)scap * 16))
+    const size_t scap = (size_t)cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
+    if (alloc((void **)&W.shadow.o_dist, scap * 16) || alloc((void **)&W.shadow.d_time, scap * 16) ||
+        alloc((void **)&W.shadow.fd_vis, scap * 16) || alloc((void **)&W.shadow.fs_, scap * 16))
         return 10;
-    W.shadow_shard_entries = scap / N_SHARDS;
+    W.shadow_shard_entries = (unsigned)(scap / N_SHARDS);
     W.overflow = W.counters + COUNTER_WORDS - 1;
     W.shard_entries = cap / N_SHARDS;
     W.capacity = cap;
-    HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
+    if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
     s->wf = W;
     return 0;
 }
@@ -1262,11 +1272,15 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_OK(hipSetDevice(s->device));
-    if (int rc = ensure_wavefront(s)) return rc;
-    const Wavefront &W = s->wf;
     const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
     const int total_tiles = tiles_x * tiles_y;
     const int n_owned = total_tiles > rank ? (total_tiles - rank + world - 1) / world : 0;
+    const bool pt = cam->path_tracing != 0;
+    // queue growth bound per camera sample: splitting fans out at depth 0, dielectrics may double per bounce
+    unsigned growth = (unsigned)(pt && cam->splitting_factor > 1 ? cam->splitting_factor : 1) * (s->has_dielectric ? 2u : 1u);
+    // room for the whole shard in one batch (plus the slack the batch planner keeps), as far as the bound allows
+    if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024)) return rc;
+    const Wavefront &W = s->wf;
     if ((unsigned long long)n_samples * 1024ull > W.capacity) {
         g_error = "NumSamples too large for the wavefront capacity (set RT_WAVEFRONT_CAPACITY)";
         return 5;
@@ -1293,10 +1307,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
 
-    const bool pt = cam->path_tracing != 0;
     const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
-    // queue growth bound per camera sample: splitting fans out at depth 0, dielectrics may double per bounce
-    unsigned growth = (unsigned)(pt && cam->splitting_factor > 1 ? cam->splitting_factor : 1) * (s->has_dielectric ? 2u : 1u);
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -1387,7 +1398,9 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     int grid_n, n_samples;
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     HIP_OK(hipSetDevice(s->device));
-    if (int rc = ensure_wavefront(s)) return rc;
+    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
+    const int total_tiles = tiles_x * tiles_y;
+    if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull)) return rc;
     const Wavefront &W = s->wf;
     const size_t n = (size_t)cam->resx * cam->resy;
     int32_t *d_shape = nullptr, *d_id = nullptr;
@@ -1404,9 +1417,8 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     HIP_OK(hipMalloc((void **)&d_t, n * 4));
     HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
+    HIP_OK(hipMemsetAsync(W.overflow, 0, sizeof(unsigned), s->stream));
     // the same generate -> trace stages as a render, first sample of every pixel only
-    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
-    const int total_tiles = tiles_x * tiles_y;
     const int tiles_max = (int)std::max(1u, W.capacity / 1024u);
     for (int tile = 0; tile < total_tiles; tile += tiles_max) {
         Batch b;
@@ -1420,7 +1432,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
         b.world = 1;
         b.still = 1;
         const unsigned slots = (unsigned)b.n_pixels;
-        HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
+        HIP_OK(hipMemsetAsync(W.counters, 0, (COUNTER_WORDS - 1) * sizeof(unsigned), s->stream));   // all but the overflow flag
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
         const unsigned grid = std::min(4096u / N_SHARDS, std::max(1u, (slots / N_SHARDS + 255) / 256)) * N_SHARDS;
         launch_trace(s, false, grid, 0, 0);
@@ -1428,10 +1440,15 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
         HIP_OK(hipGetLastError());
     }
     HIP_OK(hipEventRecord(s->ev1, s->stream));
+    HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipMemcpyAsync(shape_out, d_shape, n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipMemcpyAsync(id_out, d_id, n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipMemcpyAsync(t_out, d_t, n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
+    if (*s->host_flags) {
+        g_error = "rt_trace_primary: ray queue overflow";
+        return 6;
+    }
     float kernel_ms = 0.f;
     HIP_OK(hipEventElapsedTime(&kernel_ms, s->ev0, s->ev1));
     read_stats(s, stats, kernel_ms, kernel_ms);
