@@ -151,7 +151,12 @@ __device__ __forceinline__ void accum_add(float *accum, int slot, V v) {
     unsafeAtomicAdd(accum + 3 * (size_t)slot + 2, v.z);
 }
 
+// The frame's ray and work counters: STAT_ROWS rows of STAT_WORDS 64-bit words, one row per 128-byte line; a
+// workgroup adds to row blockIdx.x % STAT_ROWS and the host sums the rows.  (All waves of a kernel adding to one
+// address would queue up behind each other at the L2.)
+constexpr int STAT_ROWS = 64, STAT_WORDS = 16, STAT_USED = 9;
 __device__ __forceinline__ void flush_counters(const Counters &c, unsigned long long *stats, bool detailed) {
+    stats += (blockIdx.x % STAT_ROWS) * STAT_WORDS;
     uint32_t vals[9] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -845,7 +850,7 @@ template <class T> int upload(const T *src, size_t n, T **dst) {
 struct rt_scene {
     DevScene dev{};
     std::vector<void *> allocations;
-    unsigned long long *stats = nullptr;   // 9 device counters
+    unsigned long long *stats = nullptr;   // STAT_ROWS x STAT_WORDS device counters
     float *framebuffer = nullptr;
     size_t framebuffer_floats = 0;
     bool counters = false;
@@ -1176,7 +1181,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.bg, d->background_color, sizeof D.bg);
     D.bg_tex = d->background_texture;
     D.is_probe = d->is_probe;
-    if (hipMalloc((void **)&s->stats, 9 * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+    if (hipMalloc((void **)&s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         g_error = "rt_scene_create: cannot allocate stream/events";
         rt_scene_destroy(s);
@@ -1243,8 +1248,10 @@ static int check_camera(const rt_scene *s, const rt_camera_desc *cam, int &grid_
 
 static void read_stats(rt_scene *s, rt_stats *st, float kernel_ms, float total_ms) {
     if (!st) return;
-    unsigned long long v[9];
-    (void)hipMemcpy(v, s->stats, sizeof v, hipMemcpyDeviceToHost);
+    unsigned long long rows[STAT_ROWS * STAT_WORDS], v[STAT_USED] = {};
+    if (hipMemcpy(rows, s->stats, sizeof rows, hipMemcpyDeviceToHost) != hipSuccess) memset(rows, 0, sizeof rows);
+    for (int r = 0; r < STAT_ROWS; ++r)
+        for (int k = 0; k < STAT_USED; ++k) v[k] += rows[r * STAT_WORDS + k];
     memset(st, 0, sizeof *st);
     st->primary_rays = v[0];
     st->shadow_rays = v[1];
@@ -1304,7 +1311,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         dev_out = s->framebuffer;
         if (world > 1) HIP_OK(hipMemcpyAsync(dev_out, hdr_out, n_floats * sizeof(float), hipMemcpyHostToDevice, s->stream));
     }
-    HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
+    HIP_OK(hipMemsetAsync(s->stats, 0, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
 
     const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
@@ -1360,7 +1367,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
             }
             growth *= 2;
             // ray counters of the abandoned attempt are not separable; the frame's counters restart
-            HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
+            HIP_OK(hipMemsetAsync(s->stats, 0, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), s->stream));
             tile = 0;
             continue;
         }
@@ -1415,7 +1422,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     HIP_OK(hipMalloc((void **)&d_shape, n * 4));
     HIP_OK(hipMalloc((void **)&d_id, n * 4));
     HIP_OK(hipMalloc((void **)&d_t, n * 4));
-    HIP_OK(hipMemsetAsync(s->stats, 0, 9 * sizeof(unsigned long long), s->stream));
+    HIP_OK(hipMemsetAsync(s->stats, 0, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     HIP_OK(hipMemsetAsync(W.overflow, 0, sizeof(unsigned), s->stream));
     // the same generate -> trace stages as a render, first sample of every pixel only
