@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* ---- enums (values follow the reference's enum order) ---------------------------------------- */
 enum { RT_MAT_REGULAR = 0, RT_MAT_MIRROR = 1, RT_MAT_CONDUCTOR = 2, RT_MAT_DIELECTRIC = 3 }; /* src/shapes.h:20-26 */
@@ -233,6 +233,8 @@ typedef struct rt_stats {
     uint64_t texel_fetches;
     float kernel_ms;             /* device time of the render kernels of the last call */
     float total_ms;              /* wall time of the call including copies */
+    uint64_t shadow_rays_traced; /* any-hit traversals run: <= shadow_rays, light samples of a shading point whose rays are
+                                    identical bit for bit share one traversal (all do when the work counters are on) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -1272,6 +1272,7 @@ void fill_stats(const Counters &c, double ms, rt_stats *st) {
     st->texel_fetches = c.texels;
     st->kernel_ms = (float)ms;
     st->total_ms = (float)ms;
+    st->shadow_rays_traced = c.shadow;   // the reference traverses once per light sample
 }
 
 template <class T> void copy_array(std::vector<T> &dst, const T *src, int64_t n) {

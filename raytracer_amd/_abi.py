@@ -87,7 +87,7 @@ class CameraDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", u64), ("shadow_rays", u64), ("secondary_rays", u64), ("nodes_visited", u64),
                 ("triangle_tests", u64), ("sphere_tests", u64), ("plane_tests", u64), ("shaded_hits", u64),
-                ("texel_fetches", u64), ("kernel_ms", f32), ("total_ms", f32)]
+                ("texel_fetches", u64), ("kernel_ms", f32), ("total_ms", f32), ("shadow_rays_traced", u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -77,10 +77,14 @@ struct VertexBuf {      // one record per shading point that needs direct lighti
     float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it), bits(first shadow record of this pass)
 };
 
-struct ShadowQueue {    // one record per light sample with non-zero incident radiance
+struct ShadowQueue {
+    // one ray per DISTINCT shadow ray of a vertex (light samples whose origin, direction and length agree bit for
+    // bit share one: e.g. the 16 samples of a sphere light, whose sampled position is always the sphere's centre)
     float4 *o_dist;     // shadow-ray origin.xyz, distance to the light sample
     float4 *d_time;     // direction.xyz, ray time
-    float4 *fd_vis;     // diffuse term x radiance x 1/samples .xyz, visibility (written by the any-hit kernel)
+    float *vis;         // visibility, written by the any-hit trace
+    // one record per light sample with non-zero incident radiance
+    float4 *fd_ray;     // diffuse term x radiance x 1/samples .xyz, bits(index of the sample's ray)
     float4 *fs_;        // specular term x radiance x 1/samples .xyz
 };
 
@@ -154,12 +158,12 @@ __device__ __forceinline__ void accum_add(float *accum, int slot, V v) {
 // The frame's ray and work counters: STAT_ROWS rows of STAT_WORDS 64-bit words, one row per 128-byte line; a
 // workgroup adds to row blockIdx.x % STAT_ROWS and the host sums the rows.  (All waves of a kernel adding to one
 // address would queue up behind each other at the L2.)
-constexpr int STAT_ROWS = 64, STAT_WORDS = 16, STAT_USED = 9;
+constexpr int STAT_ROWS = 64, STAT_WORDS = 16, STAT_USED = 10;
 __device__ __forceinline__ void flush_counters(const Counters &c, unsigned long long *stats, bool detailed) {
     stats += (blockIdx.x % STAT_ROWS) * STAT_WORDS;
-    uint32_t vals[9] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels};
+    uint32_t vals[STAT_USED] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels, c.traced};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < STAT_USED; ++k) {
         if (!detailed && (k >= 3 && k <= 6)) continue;
         uint32_t v = wave_sum(vals[k]);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(stats + k, (unsigned long long)v);
@@ -227,7 +231,7 @@ template <bool ANY>
 __device__ __forceinline__ void ray_result(const Wavefront &W, unsigned idx, float t, int prim, float dist, float eps) {
     if (ANY) {
         const bool in_shadow = prim != -1 && t < dist - eps;   // src/ray_trace.cpp:232-241
-        ((float *)&W.shadow.fd_vis[idx])[3] = in_shadow ? 0.f : 1.f;
+        W.shadow.vis[idx] = in_shadow ? 0.f : 1.f;
     } else {
         W.hit_t[idx] = t;
         W.hit_prim[idx] = prim;
@@ -244,7 +248,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
     const unsigned room = ANY ? W.shadow_shard_entries : W.shard_entries;
     unsigned count = ctr[0];
     if (count > room) count = room;
-    unsigned *fetch = ctr + 1;   // next unclaimed entry of this shard; shares the append counter's line, zeroed with it
+    // next unclaimed entry of this shard; shares the append counter's line, zeroed with it (word 2 of a shadow line
+    // counts the light-sample records)
+    unsigned *fetch = ctr + 1;
     const unsigned base_idx = shard * room;
     const PathQueue &Q = W.q[gen & 1];
     const float eps = ANY ? S.seps : S.ieps;
@@ -671,7 +677,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 //               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
 __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
-                                                           int k_total, int k_pad, unsigned long long *__restrict__ stats) {
+                                                           int k_total, int k_pad, int share_rays, unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
@@ -682,6 +688,9 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
     const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
     const unsigned kl = lane & (unsigned)(k_pad - 1);
     const unsigned k = (unsigned)pass * 64u + kl;
+    const unsigned group_first = lane - kl;   // first lane of this lane's vertex
+    const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_first;
+    unsigned *ray_count = counter_of(W, Q_SHADOW, gen, shard), *record_count = ray_count + 2;
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
@@ -712,24 +721,42 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             }
         }
         const unsigned long long mask = __ballot(want);
-        const unsigned rl = wave_append(want, counter_of(W, Q_SHADOW, gen, shard));
+        // a sample whose ray equals, bit for bit, the ray of the vertex's previous sample with a record shares that ray
+        const unsigned long long lower = mask & group & ((1ull << lane) - 1ull);
+        const int prev = lower ? 63 - __clzll((long long)lower) : (int)lane;
+        bool same = share_rays != 0 && want && lower != 0;
+        same &= __float_as_uint(__shfl(so.x, prev, 64)) == __float_as_uint(so.x);
+        same &= __float_as_uint(__shfl(so.y, prev, 64)) == __float_as_uint(so.y);
+        same &= __float_as_uint(__shfl(so.z, prev, 64)) == __float_as_uint(so.z);
+        same &= __float_as_uint(__shfl(ldir.x, prev, 64)) == __float_as_uint(ldir.x);
+        same &= __float_as_uint(__shfl(ldir.y, prev, 64)) == __float_as_uint(ldir.y);
+        same &= __float_as_uint(__shfl(ldir.z, prev, 64)) == __float_as_uint(ldir.z);
+        same &= __float_as_uint(__shfl(dist, prev, 64)) == __float_as_uint(dist);
+        const bool owner = want && !same;   // this lane's ray gets traced
+        const unsigned long long owners = __ballot(owner);
+        const unsigned ray_local = wave_append(owner, ray_count);
+        // a sharing lane's ray is the one of the nearest owner below it (its whole run back to that owner is equal)
+        const unsigned long long owners_below = owners & ((2ull << lane) - 1ull);
+        const unsigned ray_index = shadow_base + __shfl(ray_local, owners_below ? 63 - __clzll((long long)owners_below) : 0, 64);
+        const unsigned rl = wave_append(want, record_count);
         const unsigned ri = shadow_base + rl;
         const unsigned wave_base = __shfl(ri, mask ? __ffsll((long long)mask) - 1 : 0, 64);   // record index of the wave's first record
         if (want) {
             if (rl >= W.shadow_shard_entries) {
                 *W.overflow = 1u;
             } else {
-                W.shadow.o_dist[ri] = make_float4(so.x, so.y, so.z, dist);
-                W.shadow.d_time[ri] = make_float4(ldir.x, ldir.y, ldir.z, time);
-                W.shadow.fd_vis[ri] = make_float4(fd.x, fd.y, fd.z, 0.f);
+                if (owner) {   // ray_local <= rl: there are never more rays than records
+                    ++c.traced;
+                    W.shadow.o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
+                    W.shadow.d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, time);
+                }
+                W.shadow.fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
                 W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
             }
         }
         if (vl < nv && kl == 0) {   // first lane of the vertex: where its records start and how many there are
-            const unsigned group_shift = lane;   // kl == 0 => lane is the group's first lane
-            const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_shift;
             const unsigned n = (unsigned)__popcll(mask & group);
-            const unsigned before = (unsigned)__popcll(mask & ((1ull << group_shift) - 1ull));
+            const unsigned before = (unsigned)__popcll(mask & ((1ull << group_first) - 1ull));
             ((float *)&W.vtx.ks_n[v])[3] = __uint_as_float(n);
             ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float(mask ? wave_base + before : 0u);
         }
@@ -747,9 +774,15 @@ __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen,
         const float4 ksn = W.vtx.ks_n[v], w = W.vtx.weight[v], af = W.vtx.amb_first[v];
         const unsigned n = __float_as_uint(ksn.w), first = __float_as_uint(af.w);
         V color = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
+        unsigned ray = 0xffffffffu;
+        float vis = 0.f;
         for (unsigned r = first; r < first + n && r < shadow_end; ++r) {
-            const float4 fd = W.shadow.fd_vis[r];
-            if (fd.w == 0.f) continue;
+            const float4 fd = W.shadow.fd_ray[r];
+            if (__float_as_uint(fd.w) != ray) {
+                ray = __float_as_uint(fd.w);
+                vis = W.shadow.vis[ray];
+            }
+            if (vis == 0.f) continue;
             const float4 fs = W.shadow.fs_[r];
             color = add(color, mk(fd.x, fd.y, fd.z));
             color = add(color, mk(fs.x, fs.y, fs.z));
@@ -912,7 +945,7 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
         return 10;
     const size_t scap = (size_t)cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
     if (alloc((void **)&W.shadow.o_dist, scap * 16) || alloc((void **)&W.shadow.d_time, scap * 16) ||
-        alloc((void **)&W.shadow.fd_vis, scap * 16) || alloc((void **)&W.shadow.fs_, scap * 16))
+        alloc((void **)&W.shadow.fd_ray, scap * 16) || alloc((void **)&W.shadow.fs_, scap * 16) || alloc((void **)&W.shadow.vis, scap * 4))
         return 10;
     W.shadow_shard_entries = (unsigned)(scap / N_SHARDS);
     W.overflow = W.counters + COUNTER_WORDS - 1;
@@ -1262,6 +1295,7 @@ static void read_stats(rt_scene *s, rt_stats *st, float kernel_ms, float total_m
     st->plane_tests = v[6];
     st->shaded_hits = v[7];
     st->texel_fetches = v[8];
+    st->shadow_rays_traced = v[9];
     st->kernel_ms = kernel_ms;
     st->total_ms = total_ms;
 }
@@ -1315,6 +1349,10 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     HIP_OK(hipEventRecord(s->ev0, s->stream));
 
     const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
+    // Identical shadow rays of a vertex are traced once.  With the work counters on, every light sample's ray is
+    // traced on its own so that the counts are those of the reference's loop (src/ray_trace.cpp:182-241).
+    static const bool share_env = !(getenv("RT_SHARE_SHADOW_RAYS") && atoi(getenv("RT_SHARE_SHADOW_RAYS")) == 0);
+    const int share_rays = (share_env && !s->counters) ? 1 : 0;
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -1350,7 +1388,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                 if (pass > 0)
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
-                hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, s->stats);
+                hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
                 launch_trace(s, true, grid, gen, 0);
                 hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass);
             }

@@ -54,6 +54,7 @@ struct DevScene {
 struct Counters {   // per-lane, reduced per wave at kernel end
     uint32_t primary, shadow, secondary, shaded;
     uint32_t nodes, tri, sph, pln, texels;
+    uint32_t traced;   // shadow rays actually traversed (light samples with identical rays share one)
 };
 
 struct Hit {

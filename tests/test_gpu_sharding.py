@@ -71,3 +71,24 @@ def test_full_size_path_traced_frame_properties(scene_dir):
     # a quarter-resolution render of the same camera sees the same scene: mean radiance agrees to Monte-Carlo noise
     small, _ = ren.render(sc.camera(0, resx=960, resy=540))
     assert abs(small.mean() - img.mean()) <= 0.05 * img.mean()
+
+
+@pytest.mark.parametrize("name", ["emitters", "pathtrace", "distributed"])
+def test_shared_shadow_rays_change_nothing_but_the_work(name, scene_dir):
+    """Light samples of a shading point whose shadow rays are identical share one traversal (sphere emitters:
+    the reference always aims at the sphere's centre).  Against a render with the work counters on, where every
+    sample's ray is traversed as in the reference: the same rays by the reference's count, the same image."""
+    sc = R.Scene(GS.SCENES[name][0](scene_dir))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    shared, st_shared = ren.render(cam)
+    ren.set_counters(True)
+    each, st_each = ren.render(cam)
+    assert (st_shared.primary_rays, st_shared.shadow_rays, st_shared.secondary_rays) == \
+           (st_each.primary_rays, st_each.shadow_rays, st_each.secondary_rays)
+    assert st_each.shadow_rays_traced == st_each.shadow_rays
+    assert st_shared.shadow_rays_traced <= st_shared.shadow_rays
+    if name == "emitters":
+        assert st_shared.shadow_rays_traced < st_shared.shadow_rays
+    err = np.abs(shared - each) / np.maximum(np.abs(each), 1 / 255)
+    assert err.max() <= 1e-5
