@@ -81,6 +81,24 @@ def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
     return {"value": so.total_rays / ms / 1e3, "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample, "ms": ms}
 
 
+def kernel_bytes(st):
+    """Algorithmic bytes per kernel class for one frame, from the frame's work counters.  Traversal: 32 B per node
+    visit, 36 B per triangle test, 64 B per sphere test, 24 B per plane test, 32 B ray read + 16 B hit write per ray.
+    Shading: 64 B material + 12 B framebuffer per shaded hit, 16 B per texel fetch.  Queue records at their stored
+    size: path 52 B, vertex 112 B, light-sample record 32 B, shadow ray 32 B + 4 B visibility."""
+    camera = st.primary_rays
+    paths = st.primary_rays + st.secondary_rays
+    return {
+        "generate": 64 * camera,
+        "trace_closest": st.traversal_bytes(False),
+        "shade": 60 * paths + 76 * st.shaded_hits + 16 * st.texel_fetches + 112 * st.shaded_hits + 52 * st.secondary_rays,
+        "light_setup": 112 * st.shaded_hits + 32 * st.shadow_rays + 32 * st.shadow_rays_traced,
+        "trace_any": st.traversal_bytes(True) - 12 * st.shadow_rays_traced,
+        "light_gather": 64 * st.shaded_hits + 36 * st.shadow_rays + 12 * st.shaded_hits,
+        "resolve": 12 * camera + 12 * camera,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,27 +153,34 @@ def main():
             fb.zero_()
         step()
     sync()
-    kernel_ms = 0.0
+    ren.set_profiling(True)   # HIP events around every kernel launch, on the library's own stream
     rays = 0
-    alg_bytes = 0
+    traced = 0
     t0 = time.perf_counter()
-    stats = None
     for _ in range(args.steps):
         if world > 1:
             fb.zero_()
         stats = step()
-        kernel_ms += stats.kernel_ms
         rays += stats.total_rays
+        traced += stats.total_rays - stats.shadow_rays + stats.shadow_rays_traced
     sync()
     elapsed = time.perf_counter() - t0
+    ktimes = ren.kernel_times()
+    ren.set_profiling(False)
 
-    # one extra, untimed frame with traversal counters on: algorithmic bytes per frame for the roofline
+    # one extra, untimed frame with the work counters on: algorithmic bytes for the roofline.  In this mode every
+    # light sample's shadow ray is traversed on its own, which is also the frame time without ray sharing.
     ren.set_counters(True)
-    _, sc_stats = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
+    _, cs = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
     ren.set_counters(False)
-    alg_bytes = sc_stats.algorithmic_bytes
+    unshared_ms = None
+    if world == 1:
+        os.environ["RT_SHARE_SHADOW_RAYS"] = "0"
+        _, us = ren.render(cam, out=fb.data_ptr())
+        unshared_ms = us.total_ms
+        del os.environ["RT_SHARE_SHADOW_RAYS"]
 
-    t = torch.tensor([elapsed, float(rays), kernel_ms, float(alg_bytes)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(rays), float(traced)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -163,10 +188,19 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         rays = float(tsum[1])
+        traced = float(tsum[2])
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        kernel_ms_per_launch = kernel_ms / args.steps
-        achieved = alg_bytes / (kernel_ms_per_launch * 1e-3) / 1e9 if kernel_ms_per_launch > 0 else 0.0
+        # dominant kernel = the kernel class with the largest device time in the timed steps
+        name = max(ktimes, key=lambda k: ktimes[k][1])
+        launches, total_ms = ktimes[name]
+        per_frame = kernel_bytes(cs)   # algorithmic bytes of each kernel class in one frame
+        launches_per_frame = launches / args.steps
+        bytes_per_launch = per_frame[name] / launches_per_frame
+        ms_per_launch = total_ms / launches
+        if name == "trace_any":   # the counted frame traversed every sample's ray; the timed frames shared identical ones
+            bytes_per_launch *= (stats.shadow_rays_traced / max(1, cs.shadow_rays_traced))
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
         line = {
             "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -174,11 +208,18 @@ def main():
             "config": {"workload": args.workload, "resolution": f"{cam.resx}x{cam.resy}", "spp": cam.num_samples,
                        "triangles": sc.desc.n_triangles, "bvh_nodes": sc.desc.n_bvh_nodes,
                        "renderer": "path tracing" if cam.path_tracing else "whitted", "sharding": f"tiles32/{world}"},
-            "rays_per_frame": rays / args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # rays as the reference's algorithm casts them (the unit the CPU baseline is counted in) and the
+            # traversals actually run: light samples of a shading point with bit-identical shadow rays share one
+            "rays_per_frame": rays / args.steps, "traversals_per_frame": traced / args.steps,
+            "value_traversals": traced / elapsed / 1e6,
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms_per_launch": kernel_ms_per_launch, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms_per_launch": ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launches_per_frame": launches_per_frame,
+                         "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()}},
         }
+        if unshared_ms:
+            line["without_ray_sharing"] = {"ms_per_step": unshared_ms, "value": cs.total_rays / unshared_ms / 1e3}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(R, scenegen, w, scene_dir, None)
         print(json.dumps(line), flush=True)

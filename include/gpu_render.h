@@ -234,8 +234,20 @@ typedef struct rt_stats {
     float kernel_ms;             /* device time of the render kernels of the last call */
     float total_ms;              /* wall time of the call including copies */
     uint64_t shadow_rays_traced; /* any-hit traversals run: <= shadow_rays, light samples of a shading point whose rays are
-                                    identical bit for bit share one traversal (all do when the work counters are on) */
+                                    identical bit for bit share one traversal (none do when the work counters are on) */
+    uint64_t any_hit_nodes_visited;   /* the any-hit (shadow) share of nodes_visited ... plane_tests */
+    uint64_t any_hit_triangle_tests;
+    uint64_t any_hit_sphere_tests;
+    uint64_t any_hit_plane_tests;
 } rt_stats;
+
+/* kernels of the render path, in launch order within a batch (indices of rt_kernel_times' output) */
+enum { RT_KERNEL_GENERATE = 0, RT_KERNEL_TRACE_CLOSEST = 1, RT_KERNEL_SHADE = 2, RT_KERNEL_LIGHT_SETUP = 3,
+       RT_KERNEL_TRACE_ANY = 4, RT_KERNEL_LIGHT_GATHER = 5, RT_KERNEL_RESOLVE = 6, RT_KERNEL_COUNT = 7 };
+typedef struct rt_kernel_time {
+    uint64_t launches;
+    double total_ms;     /* sum over the launches of (end event - begin event) on the library's stream */
+} rt_kernel_time;
 
 typedef struct rt_scene rt_scene;
 
@@ -265,6 +277,12 @@ int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner
  * are taken at time 0. */
 int rt_trace_primary(rt_scene *scene, const rt_camera_desc *cam, int32_t *shape_out, int32_t *id_out, float *t_out,
                      rt_stats *stats);
+
+/* Per-kernel timing of subsequent renders: every kernel launch is bracketed by two HIP events on the stream the
+ * library launches on.  Calling it (with either value) clears the totals.  rt_kernel_times fills
+ * out[RT_KERNEL_COUNT].  No reference counterpart (the reference times whole frames, src/main.cpp:557-559). */
+int rt_set_profiling(rt_scene *scene, int32_t enabled);
+int rt_kernel_times(const rt_scene *scene, rt_kernel_time *out);
 
 /* Enables per-ray traversal counters (nodes visited, primitive tests) in subsequent renders. */
 int rt_set_counters(rt_scene *scene, int32_t enabled);

@@ -71,6 +71,8 @@ def gpu_lib():
                                        C.POINTER(A.Stats)]
         g.rt_shard_owner_map.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         g.rt_set_counters.argtypes = [C.c_void_p, C.c_int32]
+        g.rt_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+        g.rt_kernel_times.argtypes = [C.c_void_p, C.POINTER(A.KernelTime)]
         g.rt_scene_destroy.argtypes = [C.c_void_p]
         g.rt_last_error.restype = C.c_char_p
         _gpu = g
@@ -157,6 +159,16 @@ class Renderer:
 
     def set_counters(self, enabled):
         self._check(self._g.rt_set_counters(self._ptr, 1 if enabled else 0), "rt_set_counters")
+
+    def set_profiling(self, enabled):
+        """Brackets every kernel launch of later renders with HIP events; clears the totals."""
+        self._check(self._g.rt_set_profiling(self._ptr, 1 if enabled else 0), "rt_set_profiling")
+
+    def kernel_times(self):
+        """{kernel name: (launches, total ms)} since set_profiling."""
+        arr = (A.KernelTime * len(A.KERNEL_NAMES))()
+        self._check(self._g.rt_kernel_times(self._ptr, arr), "rt_kernel_times")
+        return {n: (int(arr[i].launches), float(arr[i].total_ms)) for i, n in enumerate(A.KERNEL_NAMES)}
 
     def render(self, cam, out=None, rank=0, world=1):
         """Renders `cam`; returns (hdr[resy, resx, 3] float32 with row 0 = bottom row, Stats).

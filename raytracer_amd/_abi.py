@@ -87,7 +87,9 @@ class CameraDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", u64), ("shadow_rays", u64), ("secondary_rays", u64), ("nodes_visited", u64),
                 ("triangle_tests", u64), ("sphere_tests", u64), ("plane_tests", u64), ("shaded_hits", u64),
-                ("texel_fetches", u64), ("kernel_ms", f32), ("total_ms", f32), ("shadow_rays_traced", u64)]
+                ("texel_fetches", u64), ("kernel_ms", f32), ("total_ms", f32), ("shadow_rays_traced", u64),
+                ("any_hit_nodes_visited", u64), ("any_hit_triangle_tests", u64), ("any_hit_sphere_tests", u64),
+                ("any_hit_plane_tests", u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -96,6 +98,16 @@ class Stats(C.Structure):
     def total_rays(self):
         return self.primary_rays + self.shadow_rays + self.secondary_rays
 
+    def traversal_bytes(self, any_hit):
+        """Algorithmic bytes of the closest-hit (any_hit=False) or any-hit traversals under the same accounting."""
+        n, t, s, p = (self.any_hit_nodes_visited, self.any_hit_triangle_tests, self.any_hit_sphere_tests,
+                      self.any_hit_plane_tests)
+        rays = self.shadow_rays_traced
+        if not any_hit:
+            n, t, s, p = self.nodes_visited - n, self.triangle_tests - t, self.sphere_tests - s, self.plane_tests - p
+            rays = self.primary_rays + self.secondary_rays
+        return 32 * n + 36 * t + 64 * s + 24 * p + 48 * rays
+
     @property
     def algorithmic_bytes(self):
         """Traversal bytes per the fixed accounting: 32 B/node visit, 36 B/triangle test, 64 B/sphere test,
@@ -103,3 +115,10 @@ class Stats(C.Structure):
         hit + 16 B per texel fetch."""
         return (32 * self.nodes_visited + 36 * self.triangle_tests + 64 * self.sphere_tests + 24 * self.plane_tests
                 + 48 * self.total_rays + 76 * self.shaded_hits + 16 * self.texel_fetches)
+
+
+KERNEL_NAMES = ["generate", "trace_closest", "shade", "light_setup", "trace_any", "light_gather", "resolve"]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("launches", u64), ("total_ms", C.c_double)]

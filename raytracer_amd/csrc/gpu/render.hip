@@ -158,12 +158,12 @@ __device__ __forceinline__ void accum_add(float *accum, int slot, V v) {
 // The frame's ray and work counters: STAT_ROWS rows of STAT_WORDS 64-bit words, one row per 128-byte line; a
 // workgroup adds to row blockIdx.x % STAT_ROWS and the host sums the rows.  (All waves of a kernel adding to one
 // address would queue up behind each other at the L2.)
-constexpr int STAT_ROWS = 64, STAT_WORDS = 16, STAT_USED = 10;
+constexpr int STAT_ROWS = 64, STAT_WORDS = 16, STAT_USED = 14;   // words 10..13: the any-hit share of words 3..6
 __device__ __forceinline__ void flush_counters(const Counters &c, unsigned long long *stats, bool detailed) {
     stats += (blockIdx.x % STAT_ROWS) * STAT_WORDS;
-    uint32_t vals[STAT_USED] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels, c.traced};
+    uint32_t vals[10] = {c.primary, c.shadow, c.secondary, c.nodes, c.tri, c.sph, c.pln, c.shaded, c.texels, c.traced};
 #pragma unroll
-    for (int k = 0; k < STAT_USED; ++k) {
+    for (int k = 0; k < 10; ++k) {
         if (!detailed && (k >= 3 && k <= 6)) continue;
         uint32_t v = wave_sum(vals[k]);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(stats + k, (unsigned long long)v);
@@ -342,7 +342,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
             }
         }
     }
-    if (COUNT) flush_counters(c, stats, true);
+    if (COUNT) {
+        flush_counters(c, stats, true);
+        if (ANY) {   // the same work again under the any-hit words
+            unsigned long long *row = stats + (blockIdx.x % STAT_ROWS) * STAT_WORDS;
+            const uint32_t vals[4] = {c.nodes, c.tri, c.sph, c.pln};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = wave_sum(vals[k]);
+                if ((threadIdx.x & 63) == 0 && v) atomicAdd(row + 10 + k, (unsigned long long)v);
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard, unsigned local, V o, V d, float time, V thr, uint32_t key,
@@ -898,7 +909,52 @@ struct rt_scene {
     int k_total = 0, k_pad = 1;
     bool has_dielectric = false;
     unsigned trace_blocks[2][2] = {{0, 0}, {0, 0}};   // resident workgroups of trace_kernel<ANY, COUNT>, a multiple of N_SHARDS
+    // per-kernel timing (rt_set_profiling): every launch bracketed by two events on `stream`
+    bool profiling = false;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    struct Bracket {
+        int kernel;
+        hipEvent_t begin, end;
+    };
+    std::vector<Bracket> brackets;
+    double kernel_ms[RT_KERNEL_COUNT] = {};
+    unsigned long long kernel_launches[RT_KERNEL_COUNT] = {};
 };
+
+// Times one kernel launch when profiling is on: records an event before and (on destruction) after it.
+struct LaunchTimer {
+    rt_scene *s;
+    hipEvent_t end = nullptr;
+    LaunchTimer(rt_scene *scene, int kernel) : s(scene) {
+        if (!s->profiling) return;
+        while (s->event_pool.size() < s->events_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            s->event_pool.push_back(e);
+        }
+        hipEvent_t begin = s->event_pool[s->events_used++];
+        end = s->event_pool[s->events_used++];
+        (void)hipEventRecord(begin, s->stream);
+        s->brackets.push_back({kernel, begin, end});
+    }
+    ~LaunchTimer() {
+        if (end) (void)hipEventRecord(end, s->stream);
+    }
+};
+
+// After the stream has been synchronised: adds the bracketed launches to the per-kernel totals.
+static void harvest_timers(rt_scene *s) {
+    for (const auto &b : s->brackets) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, b.begin, b.end) == hipSuccess) {
+            s->kernel_ms[b.kernel] += ms;
+            ++s->kernel_launches[b.kernel];
+        }
+    }
+    s->brackets.clear();
+    s->events_used = 0;
+}
 
 constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
 
@@ -971,6 +1027,7 @@ static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, in
         blocks = std::max(1u, (unsigned)per_cu * (unsigned)cus / N_SHARDS) * N_SHARDS;
     }
     const dim3 grid(std::min(blocks, std::max(grid_limit, (unsigned)N_SHARDS)));
+    LaunchTimer timer(s, any ? RT_KERNEL_TRACE_ANY : RT_KERNEL_TRACE_CLOSEST);
     static const TraceTuning tune = [] {
         TraceTuning t{16, 16};
         if (const char *e = getenv("RT_TRACE_REFILL_MIN")) t.refill_min = std::min(64, std::max(1, atoi(e)));
@@ -1245,10 +1302,30 @@ void rt_scene_destroy(rt_scene *s) {
     if (s->host_flags) (void)hipHostFree(s->host_flags);
     if (s->stats) (void)hipFree(s->stats);
     if (s->framebuffer) (void)hipFree(s->framebuffer);
+    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+int rt_set_profiling(rt_scene *s, int32_t enabled) {
+    if (!s) return 1;
+    s->profiling = enabled != 0;
+    for (int k = 0; k < RT_KERNEL_COUNT; ++k) {
+        s->kernel_ms[k] = 0.0;
+        s->kernel_launches[k] = 0;
+    }
+    return 0;
+}
+
+int rt_kernel_times(const rt_scene *s, rt_kernel_time *out) {
+    if (!s || !out) return 1;
+    for (int k = 0; k < RT_KERNEL_COUNT; ++k) {
+        out[k].launches = s->kernel_launches[k];
+        out[k].total_ms = s->kernel_ms[k];
+    }
+    return 0;
 }
 
 int rt_set_counters(rt_scene *s, int32_t enabled) {
@@ -1296,6 +1373,10 @@ static void read_stats(rt_scene *s, rt_stats *st, float kernel_ms, float total_m
     st->shaded_hits = v[7];
     st->texel_fetches = v[8];
     st->shadow_rays_traced = v[9];
+    st->any_hit_nodes_visited = v[10];
+    st->any_hit_triangle_tests = v[11];
+    st->any_hit_sphere_tests = v[12];
+    st->any_hit_plane_tests = v[13];
     st->kernel_ms = kernel_ms;
     st->total_ms = total_ms;
 }
@@ -1351,8 +1432,8 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
     // Identical shadow rays of a vertex are traced once.  With the work counters on, every light sample's ray is
     // traced on its own so that the counts are those of the reference's loop (src/ray_trace.cpp:182-241).
-    static const bool share_env = !(getenv("RT_SHARE_SHADOW_RAYS") && atoi(getenv("RT_SHARE_SHADOW_RAYS")) == 0);
-    const int share_rays = (share_env && !s->counters) ? 1 : 0;
+    const char *share_env = getenv("RT_SHARE_SHADOW_RAYS");   // "0" traces every sample's ray (for A/B measurements)
+    const int share_rays = (!(share_env && atoi(share_env) == 0) && !s->counters) ? 1 : 0;
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -1373,31 +1454,48 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
         HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
-        hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
+        {
+            LaunchTimer timer(s, RT_KERNEL_GENERATE);
+            hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
+        }
         // consumer grids: a whole number of workgroups per shard
         const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
         const unsigned grid = per_shard * N_SHARDS;
         for (int gen = 0; gen < n_gen; ++gen) {
             launch_trace(s, false, grid, gen, pt ? 0 : 1);
-            if (pt)
-                hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
-            else
-                hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+            {
+                LaunchTimer timer(s, RT_KERNEL_SHADE);
+                if (pt)
+                    hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+                else
+                    hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+            }
             const int n_pass = (s->k_total + 63) / 64;
             for (int pass = 0; pass < n_pass; ++pass) {
                 if (pass > 0)
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
-                hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                {
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP);
+                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                }
                 launch_trace(s, true, grid, gen, 0);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
                 hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass);
             }
-            if (n_pass == 0 && !pt) hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0);   // ambient only
+            if (n_pass == 0 && !pt) {   // ambient only
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0);
+            }
         }
-        hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
+        {
+            LaunchTimer timer(s, RT_KERNEL_RESOLVE);
+            hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
+        }
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
+        harvest_timers(s);
         if (*s->host_flags) {   // a queue ran out of room: redo this batch with fewer camera samples in flight
             if (tiles_now == 1 && growth > 4096) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
