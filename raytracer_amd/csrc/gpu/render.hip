@@ -775,31 +775,57 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
     flush_counters(c, stats, false);
 }
 
-__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass) {
+// Lanes as in light_setup: k_pad lanes per vertex, lane kl holds the vertex's kl-th record (coalesced loads).  The
+// sum runs through the vertex's lanes one after the other -- lane kl takes the running colour from lane kl - 1 with
+// a one-lane wave shift and adds its own two terms -- so the additions happen in record order, as in the reference's
+// loop; the vertex's last lane ends up with the result.
+__device__ __forceinline__ float lane_below(float v) {   // value of lane - 1 (DPP wave_shr:1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass, int k_pad) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_end = (shard + 1) * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
     if (nv > W.shard_entries) nv = W.shard_entries;
-    for (unsigned vl = (blockIdx.x / N_SHARDS) * 256u + threadIdx.x; vl < nv; vl += (gridDim.x / N_SHARDS) * 256u) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned vpw = 64u / (unsigned)k_pad;
+    const unsigned wave_global = ((blockIdx.x / N_SHARDS) * 256u + threadIdx.x) >> 6;
+    const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
+    const unsigned kl = lane & (unsigned)(k_pad - 1);
+    for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
+        const unsigned vl = vbase + lane / (unsigned)k_pad;
         const unsigned v = shard_base + vl;
-        const float4 ksn = W.vtx.ks_n[v], w = W.vtx.weight[v], af = W.vtx.amb_first[v];
-        const unsigned n = __float_as_uint(ksn.w), first = __float_as_uint(af.w);
-        V color = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        unsigned ray = 0xffffffffu;
-        float vis = 0.f;
-        for (unsigned r = first; r < first + n && r < shadow_end; ++r) {
-            const float4 fd = W.shadow.fd_ray[r];
-            if (__float_as_uint(fd.w) != ray) {
-                ray = __float_as_uint(fd.w);
-                vis = W.shadow.vis[ray];
+        const bool valid = vl < nv;
+        V c = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
+        bool lit = false;
+        if (valid) {
+            const float4 af = W.vtx.amb_first[v];
+            const unsigned n = __float_as_uint(W.vtx.ks_n[v].w), r = __float_as_uint(af.w) + kl;
+            if (kl == 0 && pass == 0) c = mk(af.x, af.y, af.z);
+            if (kl < n && r < shadow_end) {
+                const float4 d4 = W.shadow.fd_ray[r];
+                if (W.shadow.vis[__float_as_uint(d4.w)] != 0.f) {
+                    const float4 s4 = W.shadow.fs_[r];
+                    lit = true;
+                    fd = mk(d4.x, d4.y, d4.z);
+                    fs = mk(s4.x, s4.y, s4.z);
+                }
             }
-            if (vis == 0.f) continue;
-            const float4 fs = W.shadow.fs_[r];
-            color = add(color, mk(fd.x, fd.y, fd.z));
-            color = add(color, mk(fs.x, fs.y, fs.z));
         }
-        if (w.w != 1.0f) color = scl(color, w.w);
-        accum_add(W.accum, __float_as_int(W.vtx.kd_slot[v].w), mul(mk(w.x, w.y, w.z), color));
+        if (kl == 0 && lit) c = add(add(c, fd), fs);
+        for (unsigned step = 1; step < (unsigned)k_pad; ++step) {
+            const V below = mk(lane_below(c.x), lane_below(c.y), lane_below(c.z));
+            if (kl == step) {
+                c = below;
+                if (lit) c = add(add(c, fd), fs);
+            }
+        }
+        if (valid && kl == (unsigned)(k_pad - 1)) {
+            const float4 w = W.vtx.weight[v];
+            if (w.w != 1.0f) c = scl(c, w.w);
+            accum_add(W.accum, __float_as_int(W.vtx.kd_slot[v].w), mul(mk(w.x, w.y, w.z), c));
+        }
     }
 }
 
@@ -1481,11 +1507,11 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                 }
                 launch_trace(s, true, grid, gen, 0);
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass, s->k_pad);
             }
             if (n_pass == 0 && !pt) {   // ambient only
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0, 1);
             }
         }
         {
