@@ -70,11 +70,11 @@ struct PathQueue {
 struct VertexBuf {      // one record per shading point that needs direct lighting
     float4 *p_time;     // position.xyz, ray time
     float4 *n_key;      // shading normal.xyz, bits(key)
-    float4 *view_mat;   // unit vector towards the ray origin .xyz, bits(material index)
+    float4 *view_mat;   // unit vector towards the ray origin .xyz, bits(BRDF selector of the material, see brdf_code)
     float4 *kd_slot;    // diffuse reflectance after textures .xyz, bits(slot)
-    float4 *ks_n;       // specular reflectance after textures .xyz, bits(number of shadow records of this pass)
+    float4 *ks_n;       // specular reflectance after textures .xyz, Phong exponent of the material
     float4 *weight;     // path throughput .xyz, LDR scale (1 or 0.004, src/ray_trace.cpp:402-405)
-    float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it), bits(first shadow record of this pass)
+    float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it)
 };
 
 struct ShadowQueue {
@@ -638,9 +638,10 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     const unsigned vi = shard_base + vl;
                     W.vtx.p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
                     W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
-                    W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(v_mat));
+                    const rt_material &vm = S.materials[v_mat];
+                    W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
                     W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot));
-                    W.vtx.ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, 0.f);
+                    W.vtx.ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
                     W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, v_scale);
                     W.vtx.amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
                 }
@@ -679,16 +680,34 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 }
 
 // ---- direct lighting = the light loop of calculate_color (src/ray_trace.cpp:182-400) in three kernels --------------
-// light_setup   one lane per (vertex, light sample of this pass): Light::get_sample, BRDF terms, and — when the
-//               incident radiance is non-zero — a shadow record, appended with wave ballots.  The k_pad lanes of a
-//               vertex sit in one wave, so its records are contiguous and in light-sample order; the first lane
-//               stores (first record, record count) in the vertex.
-// any_hit       one lane per shadow record: any-hit traversal, visibility = !(hit && t < dist - epsilon)
-// light_gather  one lane per vertex: ambient, then the visible records' diffuse and specular terms added in
+// light_setup   one lane per (vertex, light sample of this pass): Light::get_sample, BRDF terms, and -- when the
+//               incident radiance is non-zero -- a light-sample record at the fixed place (vertex, sample) plus a
+//               shadow ray, appended with wave ballots unless an earlier sample of the vertex has the same ray
+// trace (any)   one lane per shadow ray: any-hit traversal, visibility = !(hit && t < dist - epsilon)
+// light_gather  one lane per record: ambient, then the visible records' diffuse and specular terms added in
 //               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
+constexpr unsigned NO_RAY = 0xffffffffu;   // ray index of a light-sample record that has no contribution
+
+constexpr int STAGED_LIGHTS = 32;   // scenes with up to this many lights keep them (and their spheres) in LDS
+
+template <bool STAGED>
 __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
                                                            int k_total, int k_pad, int share_rays, unsigned long long *__restrict__ stats) {
+    // every lane reads its light (and the light's sphere) once per vertex: from LDS that is a short wait, from
+    // global memory a chain of three dependent fetches
+    __shared__ rt_light lds_lights[STAGED ? STAGED_LIGHTS : 1];
+    __shared__ rt_sphere lds_spheres[STAGED ? STAGED_LIGHTS : 1];
+    if (STAGED) {
+        const unsigned words = (unsigned)S.n_lights * (sizeof(rt_light) / 4);
+        for (unsigned i = threadIdx.x; i < words; i += 256) ((uint32_t *)lds_lights)[i] = ((const uint32_t *)S.lights)[i];
+        for (int li = 0; li < S.n_lights; ++li) {
+            if (S.lights[li].type != RT_LIGHT_SPHERE) continue;
+            const uint32_t *src = (const uint32_t *)&S.spheres[S.lights[li].sphere];
+            for (unsigned i = threadIdx.x; i < sizeof(rt_sphere) / 4; i += 256) ((uint32_t *)&lds_spheres[li])[i] = src[i];
+        }
+        __syncthreads();
+    }
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
@@ -699,9 +718,12 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
     const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
     const unsigned kl = lane & (unsigned)(k_pad - 1);
     const unsigned k = (unsigned)pass * 64u + kl;
+    const int li = k < (unsigned)k_total ? light_of[k] : 0;
+    const rt_light &L = STAGED ? lds_lights[li] : S.lights[li];
+    const rt_sphere *light_sphere = STAGED ? &lds_spheres[li] : (S.n_lights > 0 && S.lights[li].type == RT_LIGHT_SPHERE ? &S.spheres[S.lights[li].sphere] : nullptr);
     const unsigned group_first = lane - kl;   // first lane of this lane's vertex
     const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_first;
-    unsigned *ray_count = counter_of(W, Q_SHADOW, gen, shard), *record_count = ray_count + 2;
+    unsigned *ray_count = counter_of(W, Q_SHADOW, gen, shard);
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
@@ -716,17 +738,16 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z);
             const uint32_t key = __float_as_uint(nk.w);
             time = pt.w;
-            const rt_light &L = S.lights[light_of[k]];
             const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
             V rad;
-            light_sample(S, L, p, normal, r1, r2, rad, ldir, dist, c);
+            light_sample(S, L, light_sphere, p, normal, r1, r2, rad, ldir, dist, c);
             if (!(rad.x == 0 && rad.y == 0 && rad.z == 0)) {
                 want = true;
                 ++c.shadow;
                 so = add(p, scl(ldir, seps));
                 const float4 kds = W.vtx.kd_slot[v], ksn = W.vtx.ks_n[v];
                 const float lw = rt_div(1.0f, (float)L.samples);
-                brdf_terms(S.materials[__float_as_int(vm.w)], normal, ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z), mk(ksn.x, ksn.y, ksn.z), fd, fs);
+                brdf_terms(__float_as_int(vm.w), ksn.w, normal, ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z), mk(ksn.x, ksn.y, ksn.z), fd, fs);
                 fd = scl(mul(fd, rad), lw);
                 fs = scl(mul(fs, rad), lw);
             }
@@ -749,27 +770,22 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
         // a sharing lane's ray is the one of the nearest owner below it (its whole run back to that owner is equal)
         const unsigned long long owners_below = owners & ((2ull << lane) - 1ull);
         const unsigned ray_index = shadow_base + __shfl(ray_local, owners_below ? 63 - __clzll((long long)owners_below) : 0, 64);
-        const unsigned rl = wave_append(want, record_count);
-        const unsigned ri = shadow_base + rl;
-        const unsigned wave_base = __shfl(ri, mask ? __ffsll((long long)mask) - 1 : 0, 64);   // record index of the wave's first record
-        if (want) {
-            if (rl >= W.shadow_shard_entries) {
+        // the record of (vertex, sample) has a fixed place, k_pad per vertex; a sample without one is marked
+        const unsigned ri = shadow_base + vl * (unsigned)k_pad + kl;
+        if (vl < nv) {
+            if (ri >= shadow_base + W.shadow_shard_entries || (owner && ray_local >= W.shadow_shard_entries)) {
                 *W.overflow = 1u;
-            } else {
-                if (owner) {   // ray_local <= rl: there are never more rays than records
+            } else if (want) {
+                if (owner) {
                     ++c.traced;
                     W.shadow.o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
                     W.shadow.d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, time);
                 }
                 W.shadow.fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
                 W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
+            } else {
+                ((float *)&W.shadow.fd_ray[ri])[3] = __uint_as_float(NO_RAY);
             }
-        }
-        if (vl < nv && kl == 0) {   // first lane of the vertex: where its records start and how many there are
-            const unsigned n = (unsigned)__popcll(mask & group);
-            const unsigned before = (unsigned)__popcll(mask & ((1ull << group_first) - 1ull));
-            ((float *)&W.vtx.ks_n[v])[3] = __uint_as_float(n);
-            ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float(mask ? wave_base + before : 0u);
         }
     }
     flush_counters(c, stats, false);
@@ -783,9 +799,9 @@ __device__ __forceinline__ float lane_below(float v) {   // value of lane - 1 (D
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
-__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass, int k_pad) {
+__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass, int k_pad, int has_records) {
     const int shard = blockIdx.x % N_SHARDS;
-    const unsigned shard_base = shard * W.shard_entries, shadow_end = (shard + 1) * W.shadow_shard_entries;
+    const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries, shadow_end = shadow_base + W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
     if (nv > W.shard_entries) nv = W.shard_entries;
     const unsigned lane = threadIdx.x & 63u;
@@ -800,12 +816,14 @@ __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen,
         V c = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
         bool lit = false;
         if (valid) {
-            const float4 af = W.vtx.amb_first[v];
-            const unsigned n = __float_as_uint(W.vtx.ks_n[v].w), r = __float_as_uint(af.w) + kl;
-            if (kl == 0 && pass == 0) c = mk(af.x, af.y, af.z);
-            if (kl < n && r < shadow_end) {
+            if (kl == 0 && pass == 0) {
+                const float4 af = W.vtx.amb_first[v];
+                c = mk(af.x, af.y, af.z);
+            }
+            const unsigned r = shadow_base + vl * (unsigned)k_pad + kl;
+            if (has_records && r < shadow_end) {
                 const float4 d4 = W.shadow.fd_ray[r];
-                if (W.shadow.vis[__float_as_uint(d4.w)] != 0.f) {
+                if (__float_as_uint(d4.w) != NO_RAY && W.shadow.vis[__float_as_uint(d4.w)] != 0.f) {
                     const float4 s4 = W.shadow.fs_[r];
                     lit = true;
                     fd = mk(d4.x, d4.y, d4.z);
@@ -1503,15 +1521,18 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
                 {
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP);
-                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    if (s->dev.n_lights <= STAGED_LIGHTS)
+                        hipLaunchKernelGGL(light_setup_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    else
+                        hipLaunchKernelGGL(light_setup_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
                 }
                 launch_trace(s, true, grid, gen, 0);
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass, s->k_pad);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass, s->k_pad, 1);
             }
             if (n_pass == 0 && !pt) {   // ambient only
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0, 1);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0, 1, 0);
             }
         }
         {

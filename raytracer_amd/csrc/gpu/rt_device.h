@@ -767,8 +767,9 @@ __device__ void resolve_textures(const DevScene &S, const Surface &s, V p, const
 }
 
 // ---- lights (Light::get_sample, src/lights.cpp) ------------------------------------------------------
-__device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal, float ru, float rv, V &radiance, V &ldir,
-                             float &dist, Counters &c) {
+// `light_sphere`: the sphere of a sphere light (S.spheres[L.sphere] or a staged copy of it); unused otherwise.
+__device__ __forceinline__ void light_sample(const DevScene &S, const rt_light &L, const rt_sphere *light_sphere, V p, V normal, float ru,
+                                             float rv, V &radiance, V &ldir, float &dist, Counters &c) {
     const float pi = 3.14159265359f;
     radiance = mk(0, 0, 0);
     switch (L.type) {
@@ -864,7 +865,7 @@ __device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal
             return;
         }
         case RT_LIGHT_SPHERE: {
-            const rt_sphere &s = S.spheres[L.sphere];
+            const rt_sphere &s = *light_sphere;
             float phi = 2.0f * 3.14159265359f * ru;
             float cos_t = 1.0f - 2.0f * rv;
             float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
@@ -890,14 +891,17 @@ __device__ void light_sample(const DevScene &S, const rt_light &L, V p, V normal
 // calculate_color, src/ray_trace.cpp:154-406 (the last-blocker cache :158-159,207-226 is not used).
 // The five BRDFs of calculate_color (src/ray_trace.cpp:246-389): diffuse and specular factors for one light
 // direction, before multiplication by the incident radiance.
-__device__ void brdf_terms(const rt_material &m, V normal, V ldir, V view, V kd, V ks, V &fd, V &fs) {
+// The material enters as its BRDF selector (brdf | normalized << 8 | kdfresnel << 9) and Phong exponent.
+__device__ __forceinline__ int brdf_code(const rt_material &m) { return m.brdf | (m.normalized ? 1 << 8 : 0) | (m.kdfresnel ? 1 << 9 : 0); }
+__device__ __forceinline__ void brdf_terms(int code, float p_exp, V normal, V ldir, V view, V kd, V ks, V &fd, V &fs) {
+    const int brdf = code & 0xff;
+    const bool normalized = (code >> 8) & 1, kdfresnel = (code >> 9) & 1;
     float ndotl = max_std(dot(normal, ldir), 0.0f);
     V hv = normalize(add(ldir, view));
     fd = mk(0, 0, 0);
     fs = mk(0, 0, 0);
-    const float p_exp = m.phong_exponent;
     const float PI = 3.14159265359f;
-    switch (m.brdf) {
+    switch (brdf) {
         case RT_BRDF_ORIGINAL_BLINN_PHONG: {
             fd = scl(kd, ndotl);
             float ndoth = max_std(dot(normal, hv), 0.0f);
@@ -913,7 +917,7 @@ __device__ void brdf_terms(const rt_material &m, V normal, V ldir, V view, V kd,
         }
         case RT_BRDF_MODIFIED_BLINN_PHONG: {
             float ndoth = max_std(dot(normal, hv), 0.0f);
-            if (m.normalized) {
+            if (normalized) {
                 fd = scl(kd, 1.0f / PI * ndotl);
                 float norm = rt_div(p_exp + 8.0f, 8.0f * PI);
                 fs = scl(ks, norm * rt_pow(ndoth, p_exp) * ndotl);
@@ -926,7 +930,7 @@ __device__ void brdf_terms(const rt_material &m, V normal, V ldir, V view, V kd,
         case RT_BRDF_MODIFIED_PHONG: {
             V R = reflect_dir(normal, scl(ldir, -1.0f), 0.f, 0);
             float rdoth = max_std(dot(R, view), 0.0f);
-            if (m.normalized) {
+            if (normalized) {
                 fd = scl(kd, 1.0f / PI * ndotl);
                 float norm = rt_div(p_exp + 2.0f, 2.0f * PI);
                 fs = scl(ks, norm * rt_pow(rdoth, p_exp) * ndotl);
@@ -954,7 +958,7 @@ __device__ void brdf_terms(const rt_material &m, V normal, V ldir, V view, V kd,
                 float denom = 4.0f * ndotv;
                 fs = scl(F, rt_div(D * G, denom));
             }
-            if (m.kdfresnel)
+            if (kdfresnel)
                 fd = mul(scl(kd, ndotl), sub(one, F));
             else
                 fd = scl(kd, 1.0f / PI * ndotl);
