@@ -71,10 +71,10 @@ struct VertexBuf {      // one record per shading point that needs direct lighti
     float4 *p_time;     // position.xyz, ray time
     float4 *n_key;      // shading normal.xyz, bits(key)
     float4 *view_mat;   // unit vector towards the ray origin .xyz, bits(BRDF selector of the material, see brdf_code)
-    float4 *kd_slot;    // diffuse reflectance after textures .xyz, bits(slot)
+    float4 *kd_slot;    // diffuse reflectance after textures .xyz, bits(slot | 1 << 31 when the 0.004 LDR scale applies, src/ray_trace.cpp:402-405)
     float4 *ks_n;       // specular reflectance after textures .xyz, Phong exponent of the material
-    float4 *weight;     // path throughput .xyz, LDR scale (1 or 0.004, src/ray_trace.cpp:402-405)
-    float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it)
+    float4 *weight;     // path throughput .xyz, bits(samples 32..63 of this pass that have a record)
+    float4 *amb_first;  // ambient term .xyz (zero when calculate_color excludes it), bits(samples 0..31 that have a record)
 };
 
 struct ShadowQueue {
@@ -640,9 +640,9 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
                     const rt_material &vm = S.materials[v_mat];
                     W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
-                    W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot));
+                    W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot | (v_scale != 1.0f ? (int)0x80000000 : 0)));
                     W.vtx.ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
-                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, v_scale);
+                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
                     W.vtx.amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
                 }
             }
@@ -687,8 +687,6 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 // light_gather  one lane per record: ambient, then the visible records' diffuse and specular terms added in
 //               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
-constexpr unsigned NO_RAY = 0xffffffffu;   // ray index of a light-sample record that has no contribution
-
 constexpr int STAGED_LIGHTS = 32;   // scenes with up to this many lights keep them (and their spheres) in LDS
 
 template <bool STAGED>
@@ -770,7 +768,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
         // a sharing lane's ray is the one of the nearest owner below it (its whole run back to that owner is equal)
         const unsigned long long owners_below = owners & ((2ull << lane) - 1ull);
         const unsigned ray_index = shadow_base + __shfl(ray_local, owners_below ? 63 - __clzll((long long)owners_below) : 0, 64);
-        // the record of (vertex, sample) has a fixed place, k_pad per vertex; a sample without one is marked
+        // the record of (vertex, sample) has a fixed place, k_pad per vertex
         const unsigned ri = shadow_base + vl * (unsigned)k_pad + kl;
         if (vl < nv) {
             if (ri >= shadow_base + W.shadow_shard_entries || (owner && ray_local >= W.shadow_shard_entries)) {
@@ -783,8 +781,11 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 }
                 W.shadow.fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
                 W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
-            } else {
-                ((float *)&W.shadow.fd_ray[ri])[3] = __uint_as_float(NO_RAY);
+            }
+            if (kl == 0) {   // first lane of the vertex: which of its samples have a record
+                const unsigned long long have = (mask & group) >> group_first;
+                ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float((unsigned)have);
+                ((float *)&W.vtx.weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
             }
         }
     }
@@ -813,36 +814,29 @@ __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen,
         const unsigned vl = vbase + lane / (unsigned)k_pad;
         const unsigned v = shard_base + vl;
         const bool valid = vl < nv;
-        V c = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
+        const unsigned vc = valid ? v : shard_base;   // a safe place to read for lanes past the end
+        const float4 af = W.vtx.amb_first[vc], w = W.vtx.weight[vc];
+        const int slot_scale = __float_as_int(W.vtx.kd_slot[vc].w);
+        const unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
+        const unsigned r = shadow_base + vl * (unsigned)k_pad + kl;
+        V c = (valid && kl == 0 && pass == 0) ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
         bool lit = false;
-        if (valid) {
-            if (kl == 0 && pass == 0) {
-                const float4 af = W.vtx.amb_first[v];
-                c = mk(af.x, af.y, af.z);
-            }
-            const unsigned r = shadow_base + vl * (unsigned)k_pad + kl;
-            if (has_records && r < shadow_end) {
-                const float4 d4 = W.shadow.fd_ray[r];
-                if (__float_as_uint(d4.w) != NO_RAY && W.shadow.vis[__float_as_uint(d4.w)] != 0.f) {
-                    const float4 s4 = W.shadow.fs_[r];
-                    lit = true;
-                    fd = mk(d4.x, d4.y, d4.z);
-                    fs = mk(s4.x, s4.y, s4.z);
-                }
-            }
+        float4 d4 = make_float4(0, 0, 0, 0), s4 = d4;
+        if (valid && ((have >> kl) & 1ull) && r < shadow_end) {   // only records that exist are read
+            d4 = W.shadow.fd_ray[r];
+            s4 = W.shadow.fs_[r];
+            lit = W.shadow.vis[__float_as_uint(d4.w)] != 0.f;
         }
-        if (kl == 0 && lit) c = add(add(c, fd), fs);
+        // a record that does not count adds +0 twice, which leaves a sum of non-negative terms as it is
+        const V fd = lit ? mk(d4.x, d4.y, d4.z) : mk(0, 0, 0), fs = lit ? mk(s4.x, s4.y, s4.z) : mk(0, 0, 0);
+        if (kl == 0) c = add(add(c, fd), fs);
         for (unsigned step = 1; step < (unsigned)k_pad; ++step) {
-            const V below = mk(lane_below(c.x), lane_below(c.y), lane_below(c.z));
-            if (kl == step) {
-                c = below;
-                if (lit) c = add(add(c, fd), fs);
-            }
+            const V next = add(add(mk(lane_below(c.x), lane_below(c.y), lane_below(c.z)), fd), fs);
+            if (kl == step) c = next;
         }
         if (valid && kl == (unsigned)(k_pad - 1)) {
-            const float4 w = W.vtx.weight[v];
-            if (w.w != 1.0f) c = scl(c, w.w);
-            accum_add(W.accum, __float_as_int(W.vtx.kd_slot[v].w), mul(mk(w.x, w.y, w.z), c));
+            if (slot_scale < 0) c = scl(c, 0.004f);
+            accum_add(W.accum, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
         }
     }
 }
