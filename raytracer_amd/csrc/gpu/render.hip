@@ -680,164 +680,159 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 }
 
 // ---- direct lighting = the light loop of calculate_color (src/ray_trace.cpp:182-400) in three kernels --------------
-// light_setup   one lane per (vertex, light sample of this pass): Light::get_sample, BRDF terms, and -- when the
-//               incident radiance is non-zero -- a light-sample record at the fixed place (vertex, sample) plus a
-//               shadow ray, appended with wave ballots unless an earlier sample of the vertex has the same ray
+// light_setup   one lane per vertex, looping over the light samples of this pass (so the light is the same for the
+//               whole wave and its data comes through scalar loads): Light::get_sample, BRDF terms, and -- when the
+//               incident radiance is non-zero -- a light-sample record plus a shadow ray, appended with wave
+//               ballots unless the vertex's previous record has the same ray
 // trace (any)   one lane per shadow ray: any-hit traversal, visibility = !(hit && t < dist - epsilon)
-// light_gather  one lane per record: ambient, then the visible records' diffuse and specular terms added in
+// light_gather  one lane per vertex: ambient, then the visible records' diffuse and specular terms added in
 //               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
-constexpr int STAGED_LIGHTS = 32;   // scenes with up to this many lights keep them (and their spheres) in LDS
+// Records are stored per block of 64 vertices, sample-major: record (block, sample, lane), so that both kernels
+// read and write 64 consecutive records at a time.
+__device__ __forceinline__ unsigned record_index(unsigned shadow_base, unsigned vbase, unsigned k_pad, unsigned kl, unsigned lane) {
+    return shadow_base + (vbase * k_pad + kl * 64u) + lane;   // vbase is a multiple of 64
+}
 
-template <bool STAGED>
 __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
                                                            int k_total, int k_pad, int share_rays, unsigned long long *__restrict__ stats) {
-    // every lane reads its light (and the light's sphere) once per vertex: from LDS that is a short wait, from
-    // global memory a chain of three dependent fetches
-    __shared__ rt_light lds_lights[STAGED ? STAGED_LIGHTS : 1];
-    __shared__ rt_sphere lds_spheres[STAGED ? STAGED_LIGHTS : 1];
-    if (STAGED) {
-        const unsigned words = (unsigned)S.n_lights * (sizeof(rt_light) / 4);
-        for (unsigned i = threadIdx.x; i < words; i += 256) ((uint32_t *)lds_lights)[i] = ((const uint32_t *)S.lights)[i];
-        for (int li = 0; li < S.n_lights; ++li) {
-            if (S.lights[li].type != RT_LIGHT_SPHERE) continue;
-            const uint32_t *src = (const uint32_t *)&S.spheres[S.lights[li].sphere];
-            for (unsigned i = threadIdx.x; i < sizeof(rt_sphere) / 4; i += 256) ((uint32_t *)&lds_spheres[li])[i] = src[i];
-        }
-        __syncthreads();
-    }
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
     if (nv > W.shard_entries) nv = W.shard_entries;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned vpw = 64u / (unsigned)k_pad;   // vertices per wave
     const unsigned wave_global = ((blockIdx.x / N_SHARDS) * 256u + threadIdx.x) >> 6;   // wave number within the shard
     const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
-    const unsigned kl = lane & (unsigned)(k_pad - 1);
-    const unsigned k = (unsigned)pass * 64u + kl;
-    const int li = k < (unsigned)k_total ? light_of[k] : 0;
-    const rt_light &L = STAGED ? lds_lights[li] : S.lights[li];
-    const rt_sphere *light_sphere = STAGED ? &lds_spheres[li] : (S.n_lights > 0 && S.lights[li].type == RT_LIGHT_SPHERE ? &S.spheres[S.lights[li].sphere] : nullptr);
-    const unsigned group_first = lane - kl;   // first lane of this lane's vertex
-    const unsigned long long group = (k_pad == 64 ? ~0ull : ((1ull << k_pad) - 1ull)) << group_first;
+    const int k0 = pass * 64, kn = min(k_total - k0, 64);
     unsigned *ray_count = counter_of(W, Q_SHADOW, gen, shard);
     Counters c;
     memset(&c, 0, sizeof c);
     const float seps = S.seps;
-    for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
-        const unsigned vl = vbase + lane / (unsigned)k_pad;
-        const unsigned v = shard_base + vl;
-        bool want = false;
-        V so = mk(0, 0, 0), ldir = mk(0, 0, 0), fd = mk(0, 0, 0), fs = mk(0, 0, 0);
-        float dist = 0.f, time = 0.f;
-        if (vl < nv && k < (unsigned)k_total) {
-            const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v];
-            const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z);
-            const uint32_t key = __float_as_uint(nk.w);
-            time = pt.w;
+    for (unsigned vbase = wave_global * 64u; vbase < nv; vbase += n_waves * 64u) {
+        const unsigned vl = vbase + lane;
+        const bool valid = vl < nv;
+        const unsigned v = shard_base + (valid ? vl : vbase);
+        const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v], kds = W.vtx.kd_slot[v], ksn = W.vtx.ks_n[v];
+        const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z);
+        const V kd = mk(kds.x, kds.y, kds.z), ks = mk(ksn.x, ksn.y, ksn.z);
+        const uint32_t key = __float_as_uint(nk.w);
+        const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
+        if (!room) *W.overflow = 1u;
+        unsigned long long have = 0;
+        // the vertex's previous record: its ray, for sharing.  Two samples have the same ray exactly when they belong
+        // to the same light and that light's position does not depend on the sample.
+        unsigned prev_ray = 0;
+        int prev_light = -1;   // light of the vertex's previous record when it is such a light, else -1
+        // a sphere light's direction, distance and BRDF factors do not depend on the sample: kept across its samples
+        int kept_light = -1;
+        bool kept_brdf = false;
+        V kept_ldir = mk(0, 0, 0), kept_fd = mk(0, 0, 0), kept_fs = mk(0, 0, 0);
+        float kept_dist = 0.f, kept_d2 = 0.f;
+        for (int kl = 0; kl < kn; ++kl) {
+            const unsigned k = (unsigned)(k0 + kl);
+            const int li = light_of[k];
+            const rt_light &L = S.lights[li];
             const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
-            V rad;
-            light_sample(S, L, light_sphere, p, normal, r1, r2, rad, ldir, dist, c);
-            if (!(rad.x == 0 && rad.y == 0 && rad.z == 0)) {
-                want = true;
+            V rad, ldir, fd = mk(0, 0, 0), fs = mk(0, 0, 0);
+            float dist;
+            bool want;
+            if (L.type == RT_LIGHT_SPHERE) {
+                const rt_sphere &sph = S.spheres[L.sphere];
+                if (li != kept_light) {
+                    kept_light = li;
+                    kept_brdf = false;
+                    sphere_light_geometry(sph, p, kept_ldir, kept_dist, kept_d2);
+                }
+                ldir = kept_ldir;
+                dist = kept_dist;
+                rad = sphere_light_radiance(L, sph, ldir, kept_d2, r1, r2);
+                want = valid && !(rad.x == 0 && rad.y == 0 && rad.z == 0);
+                if (want) {
+                    if (!kept_brdf) {
+                        kept_brdf = true;
+                        brdf_terms(__float_as_int(vm.w), ksn.w, normal, ldir, view, kd, ks, kept_fd, kept_fs);
+                    }
+                    fd = kept_fd;
+                    fs = kept_fs;
+                }
+            } else {
+                light_sample(S, L, nullptr, p, normal, r1, r2, rad, ldir, dist, c);
+                want = valid && !(rad.x == 0 && rad.y == 0 && rad.z == 0);
+                if (want) brdf_terms(__float_as_int(vm.w), ksn.w, normal, ldir, view, kd, ks, fd, fs);
+            }
+            V so = mk(0, 0, 0);
+            if (want) {
                 ++c.shadow;
                 so = add(p, scl(ldir, seps));
-                const float4 kds = W.vtx.kd_slot[v], ksn = W.vtx.ks_n[v];
                 const float lw = rt_div(1.0f, (float)L.samples);
-                brdf_terms(__float_as_int(vm.w), ksn.w, normal, ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z), mk(ksn.x, ksn.y, ksn.z), fd, fs);
                 fd = scl(mul(fd, rad), lw);
                 fs = scl(mul(fs, rad), lw);
+                have |= 1ull << kl;
             }
-        }
-        const unsigned long long mask = __ballot(want);
-        // a sample whose ray equals, bit for bit, the ray of the vertex's previous sample with a record shares that ray
-        const unsigned long long lower = mask & group & ((1ull << lane) - 1ull);
-        const int prev = lower ? 63 - __clzll((long long)lower) : (int)lane;
-        bool same = share_rays != 0 && want && lower != 0;
-        same &= __float_as_uint(__shfl(so.x, prev, 64)) == __float_as_uint(so.x);
-        same &= __float_as_uint(__shfl(so.y, prev, 64)) == __float_as_uint(so.y);
-        same &= __float_as_uint(__shfl(so.z, prev, 64)) == __float_as_uint(so.z);
-        same &= __float_as_uint(__shfl(ldir.x, prev, 64)) == __float_as_uint(ldir.x);
-        same &= __float_as_uint(__shfl(ldir.y, prev, 64)) == __float_as_uint(ldir.y);
-        same &= __float_as_uint(__shfl(ldir.z, prev, 64)) == __float_as_uint(ldir.z);
-        same &= __float_as_uint(__shfl(dist, prev, 64)) == __float_as_uint(dist);
-        const bool owner = want && !same;   // this lane's ray gets traced
-        const unsigned long long owners = __ballot(owner);
-        const unsigned ray_local = wave_append(owner, ray_count);
-        // a sharing lane's ray is the one of the nearest owner below it (its whole run back to that owner is equal)
-        const unsigned long long owners_below = owners & ((2ull << lane) - 1ull);
-        const unsigned ray_index = shadow_base + __shfl(ray_local, owners_below ? 63 - __clzll((long long)owners_below) : 0, 64);
-        // the record of (vertex, sample) has a fixed place, k_pad per vertex
-        const unsigned ri = shadow_base + vl * (unsigned)k_pad + kl;
-        if (vl < nv) {
-            if (ri >= shadow_base + W.shadow_shard_entries || (owner && ray_local >= W.shadow_shard_entries)) {
-                *W.overflow = 1u;
-            } else if (want) {
+            // a sample whose ray is the ray of the vertex's previous record shares it: same origin, direction and length,
+            // computed from the same inputs by the same instructions
+            const bool fixed_position = L.type == RT_LIGHT_SPHERE || L.type == RT_LIGHT_POINT || L.type == RT_LIGHT_SPOT || L.type == RT_LIGHT_DIRECTIONAL;
+            const bool same = share_rays != 0 && want && fixed_position && prev_light == li;
+            const bool owner = want && !same;   // this sample's ray gets traced
+            const unsigned ray_local = wave_append(owner, ray_count);
+            if (owner && ray_local >= W.shadow_shard_entries) *W.overflow = 1u;
+            if (want && room) {
+                unsigned ray_index = prev_ray;
                 if (owner) {
+                    ray_index = shadow_base + min(ray_local, W.shadow_shard_entries - 1u);
                     ++c.traced;
                     W.shadow.o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
-                    W.shadow.d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, time);
+                    W.shadow.d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, pt.w);
                 }
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
                 W.shadow.fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
                 W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
+                prev_ray = ray_index;
+                prev_light = fixed_position ? li : -1;
             }
-            if (kl == 0) {   // first lane of the vertex: which of its samples have a record
-                const unsigned long long have = (mask & group) >> group_first;
-                ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float((unsigned)have);
-                ((float *)&W.vtx.weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
-            }
+        }
+        if (valid) {   // which of the vertex's samples have a record
+            ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float((unsigned)have);
+            ((float *)&W.vtx.weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
         }
     }
     flush_counters(c, stats, false);
 }
 
-// Lanes as in light_setup: k_pad lanes per vertex, lane kl holds the vertex's kl-th record (coalesced loads).  The
-// sum runs through the vertex's lanes one after the other -- lane kl takes the running colour from lane kl - 1 with
-// a one-lane wave shift and adds its own two terms -- so the additions happen in record order, as in the reference's
-// loop; the vertex's last lane ends up with the result.
-__device__ __forceinline__ float lane_below(float v) {   // value of lane - 1 (DPP wave_shr:1)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-
 __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass, int k_pad, int has_records) {
     const int shard = blockIdx.x % N_SHARDS;
-    const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries, shadow_end = shadow_base + W.shadow_shard_entries;
+    const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
     if (nv > W.shard_entries) nv = W.shard_entries;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned vpw = 64u / (unsigned)k_pad;
     const unsigned wave_global = ((blockIdx.x / N_SHARDS) * 256u + threadIdx.x) >> 6;
     const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
-    const unsigned kl = lane & (unsigned)(k_pad - 1);
-    for (unsigned vbase = wave_global * vpw; vbase < nv; vbase += n_waves * vpw) {
-        const unsigned vl = vbase + lane / (unsigned)k_pad;
+    for (unsigned vbase = wave_global * 64u; vbase < nv; vbase += n_waves * 64u) {
+        const unsigned vl = vbase + lane;
+        if (vl >= nv) continue;
         const unsigned v = shard_base + vl;
-        const bool valid = vl < nv;
-        const unsigned vc = valid ? v : shard_base;   // a safe place to read for lanes past the end
-        const float4 af = W.vtx.amb_first[vc], w = W.vtx.weight[vc];
-        const int slot_scale = __float_as_int(W.vtx.kd_slot[vc].w);
-        const unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
-        const unsigned r = shadow_base + vl * (unsigned)k_pad + kl;
-        V c = (valid && kl == 0 && pass == 0) ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        bool lit = false;
-        float4 d4 = make_float4(0, 0, 0, 0), s4 = d4;
-        if (valid && ((have >> kl) & 1ull) && r < shadow_end) {   // only records that exist are read
-            d4 = W.shadow.fd_ray[r];
-            s4 = W.shadow.fs_[r];
-            lit = W.shadow.vis[__float_as_uint(d4.w)] != 0.f;
+        const float4 af = W.vtx.amb_first[v], w = W.vtx.weight[v];
+        const int slot_scale = __float_as_int(W.vtx.kd_slot[v].w);
+        unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
+        if (record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) >= shadow_base + W.shadow_shard_entries) have = 0;
+        V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
+        unsigned ray = 0xffffffffu;
+        float vis = 0.f;
+        for (int kl = 0; kl < k_pad; ++kl) {
+            if (!((have >> kl) & 1ull)) continue;
+            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
+            const float4 fd = W.shadow.fd_ray[ri];
+            if (__float_as_uint(fd.w) != ray) {
+                ray = __float_as_uint(fd.w);
+                vis = W.shadow.vis[ray];
+            }
+            if (vis == 0.f) continue;
+            const float4 fs = W.shadow.fs_[ri];
+            c = add(c, mk(fd.x, fd.y, fd.z));
+            c = add(c, mk(fs.x, fs.y, fs.z));
         }
-        // a record that does not count adds +0 twice, which leaves a sum of non-negative terms as it is
-        const V fd = lit ? mk(d4.x, d4.y, d4.z) : mk(0, 0, 0), fs = lit ? mk(s4.x, s4.y, s4.z) : mk(0, 0, 0);
-        if (kl == 0) c = add(add(c, fd), fs);
-        for (unsigned step = 1; step < (unsigned)k_pad; ++step) {
-            const V next = add(add(mk(lane_below(c.x), lane_below(c.y), lane_below(c.z)), fd), fs);
-            if (kl == step) c = next;
-        }
-        if (valid && kl == (unsigned)(k_pad - 1)) {
-            if (slot_scale < 0) c = scl(c, 0.004f);
-            accum_add(W.accum, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
-        }
+        if (slot_scale < 0) c = scl(c, 0.004f);
+        accum_add(W.accum, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
     }
 }
 
@@ -988,6 +983,8 @@ static void harvest_timers(rt_scene *s) {
         if (hipEventElapsedTime(&ms, b.begin, b.end) == hipSuccess) {
             s->kernel_ms[b.kernel] += ms;
             ++s->kernel_launches[b.kernel];
+            static const bool verbose = getenv("RT_PROFILE_LAUNCHES") != nullptr;   // diagnostic: one line per launch
+            if (verbose) fprintf(stderr, "launch kernel %d: %.3f ms\n", b.kernel, ms);
         }
     }
     s->brackets.clear();
@@ -1515,10 +1512,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
                 {
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP);
-                    if (s->dev.n_lights <= STAGED_LIGHTS)
-                        hipLaunchKernelGGL(light_setup_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
-                    else
-                        hipLaunchKernelGGL(light_setup_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
                 }
                 launch_trace(s, true, grid, gen, 0);
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);

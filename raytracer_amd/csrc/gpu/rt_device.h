@@ -767,6 +767,27 @@ __device__ void resolve_textures(const DevScene &S, const Surface &s, V p, const
 }
 
 // ---- lights (Light::get_sample, src/lights.cpp) ------------------------------------------------------
+// SphereLight::get_sample (src/lights.cpp:393-461) in two parts.  The reference transforms the scalar copies of
+// the sampled point, which are still zero (:418-422): the position used is model * (0,0,0,1), so direction and
+// distance depend on the shading point only, and the random numbers only turn the emitter normal.
+__device__ __forceinline__ void sphere_light_geometry(const rt_sphere &s, V p, V &ldir, float &dist, float &d2) {
+    const V sp = xpoint(s.model, mk(0, 0, 0));
+    const V du = sub(sp, p);
+    d2 = dot(du, du);
+    dist = rt_sqrt(d2);
+    ldir = scl(du, rt_div(1.0f, dist));
+}
+__device__ __forceinline__ V sphere_light_radiance(const rt_light &L, const rt_sphere &s, V ldir, float d2, float ru, float rv) {
+    const float phi = 2.0f * 3.14159265359f * ru;
+    const float cos_t = 1.0f - 2.0f * rv;
+    const float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
+    const V unit = mk(sin_t * rt_cos(phi), sin_t * rt_sin(phi), cos_t);
+    const V nl = normalize(xdir(s.normal, unit));
+    const float cos_l = dot(nl, scl(ldir, -1.0f));
+    if (cos_l <= 0.0f) return mk(0, 0, 0);
+    return scl(mk(L.color), rt_div(L.area * cos_l, d2));
+}
+
 // `light_sphere`: the sphere of a sphere light (S.spheres[L.sphere] or a staged copy of it); unused otherwise.
 __device__ __forceinline__ void light_sample(const DevScene &S, const rt_light &L, const rt_sphere *light_sphere, V p, V normal, float ru,
                                              float rv, V &radiance, V &ldir, float &dist, Counters &c) {
@@ -865,22 +886,9 @@ __device__ __forceinline__ void light_sample(const DevScene &S, const rt_light &
             return;
         }
         case RT_LIGHT_SPHERE: {
-            const rt_sphere &s = *light_sphere;
-            float phi = 2.0f * 3.14159265359f * ru;
-            float cos_t = 1.0f - 2.0f * rv;
-            float sin_t = rt_sqrt(max_std(0.0f, 1.0f - cos_t * cos_t));
-            V unit = mk(sin_t * rt_cos(phi), sin_t * rt_sin(phi), cos_t);
-            // the reference transforms the scalar copies of the sampled point, which are still zero
-            // (src/lights.cpp:418-422): the position used is model * (0,0,0,1)
-            V sp = xpoint(s.model, mk(0, 0, 0));
-            V nl = normalize(xdir(s.normal, unit));
-            V du = sub(sp, p);
-            float d2 = dot(du, du);
-            dist = rt_sqrt(d2);
-            ldir = scl(du, rt_div(1.0f, dist));
-            float cos_l = dot(nl, scl(ldir, -1.0f));
-            if (cos_l <= 0.0f) return;
-            radiance = scl(mk(L.color), rt_div(L.area * cos_l, d2));
+            float d2;
+            sphere_light_geometry(*light_sphere, p, ldir, dist, d2);
+            radiance = sphere_light_radiance(L, *light_sphere, ldir, d2, ru, rv);
             return;
         }
     }
