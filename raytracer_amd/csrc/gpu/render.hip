@@ -92,8 +92,8 @@ struct Wavefront {
     PathQueue q[2];
     float *hit_t;
     int *hit_prim;
-    VertexBuf vtx;
-    ShadowQueue shadow;
+    VertexBuf vtx[2];         // by generation parity: the direct lighting of generation g runs beside the
+    ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
     unsigned shadow_shard_entries;   // shadow records per shard
     float *accum;             // 3 floats per slot
     unsigned *counters;       // [3 kinds][MAX_GENERATIONS + 1][N_SHARDS] entry counts, one 128-byte line each
@@ -228,10 +228,10 @@ struct TraceTuning {
 
 // A finished ray's record: visibility of the light sample (any hit) or the closest hit.
 template <bool ANY>
-__device__ __forceinline__ void ray_result(const Wavefront &W, unsigned idx, float t, int prim, float dist, float eps) {
+__device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned idx, float t, int prim, float dist, float eps) {
     if (ANY) {
         const bool in_shadow = prim != -1 && t < dist - eps;   // src/ray_trace.cpp:232-241
-        W.shadow.vis[idx] = in_shadow ? 0.f : 1.f;
+        W.shadow[gen & 1].vis[idx] = in_shadow ? 0.f : 1.f;
     } else {
         W.hit_t[idx] = t;
         W.hit_prim[idx] = prim;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
                         idx = base_idx + mine;
                         bool go;
                         if (ANY) {
-                            const float4 od = W.shadow.o_dist[idx], dt = W.shadow.d_time[idx];
+                            const float4 od = W.shadow[gen & 1].o_dist[idx], dt = W.shadow[gen & 1].d_time[idx];
                             r.ox = od.x, r.oy = od.y, r.oz = od.z;
                             r.dx = dt.x, r.dy = dt.y, r.dz = dt.z;
                             r.time = dt.w;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
                             }
                         }
                         if (!go) {
-                            ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                            ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                             r.cur = REF_IDLE;
                         }
                     }
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
         }
         if (r.cur == REF_POP) {
             if (!stack_pop<(!ANY || COUNT), COUNT>(r, lds, spill, c)) {
-                ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                 r.cur = REF_IDLE;
             }
         }
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))
                     done = ANY;
                 }
                 if (done) {
-                    ray_result<ANY>(W, idx, r.t, r.prim, dist, eps);
+                    ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                     r.cur = REF_IDLE;
                 } else {
                     r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
@@ -636,14 +636,14 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     *W.overflow = 1u;
                 } else {
                     const unsigned vi = shard_base + vl;
-                    W.vtx.p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
-                    W.vtx.n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
+                    W.vtx[gen & 1].p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
+                    W.vtx[gen & 1].n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
                     const rt_material &vm = S.materials[v_mat];
-                    W.vtx.view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
-                    W.vtx.kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot | (v_scale != 1.0f ? (int)0x80000000 : 0)));
-                    W.vtx.ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
-                    W.vtx.weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
-                    W.vtx.amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
+                    W.vtx[gen & 1].view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
+                    W.vtx[gen & 1].kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot | (v_scale != 1.0f ? (int)0x80000000 : 0)));
+                    W.vtx[gen & 1].ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
+                    W.vtx[gen & 1].weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
+                    W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
                 }
             }
         }
@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
         const unsigned vl = vbase + lane;
         const bool valid = vl < nv;
         const unsigned v = shard_base + (valid ? vl : vbase);
-        const float4 pt = W.vtx.p_time[v], nk = W.vtx.n_key[v], vm = W.vtx.view_mat[v], kds = W.vtx.kd_slot[v], ksn = W.vtx.ks_n[v];
+        const float4 pt = W.vtx[gen & 1].p_time[v], nk = W.vtx[gen & 1].n_key[v], vm = W.vtx[gen & 1].view_mat[v], kds = W.vtx[gen & 1].kd_slot[v], ksn = W.vtx[gen & 1].ks_n[v];
         const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z);
         const V kd = mk(kds.x, kds.y, kds.z), ks = mk(ksn.x, ksn.y, ksn.z);
         const uint32_t key = __float_as_uint(nk.w);
@@ -781,19 +781,19 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 if (owner) {
                     ray_index = shadow_base + min(ray_local, W.shadow_shard_entries - 1u);
                     ++c.traced;
-                    W.shadow.o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
-                    W.shadow.d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, pt.w);
+                    W.shadow[gen & 1].o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
+                    W.shadow[gen & 1].d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, pt.w);
                 }
                 const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
-                W.shadow.fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
-                W.shadow.fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
+                W.shadow[gen & 1].fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
+                W.shadow[gen & 1].fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
                 prev_ray = ray_index;
                 prev_light = fixed_position ? li : -1;
             }
         }
         if (valid) {   // which of the vertex's samples have a record
-            ((float *)&W.vtx.amb_first[v])[3] = __uint_as_float((unsigned)have);
-            ((float *)&W.vtx.weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
+            ((float *)&W.vtx[gen & 1].amb_first[v])[3] = __uint_as_float((unsigned)have);
+            ((float *)&W.vtx[gen & 1].weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
         }
     }
     flush_counters(c, stats, false);
@@ -811,8 +811,8 @@ __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen,
         const unsigned vl = vbase + lane;
         if (vl >= nv) continue;
         const unsigned v = shard_base + vl;
-        const float4 af = W.vtx.amb_first[v], w = W.vtx.weight[v];
-        const int slot_scale = __float_as_int(W.vtx.kd_slot[v].w);
+        const float4 af = W.vtx[gen & 1].amb_first[v], w = W.vtx[gen & 1].weight[v];
+        const int slot_scale = __float_as_int(W.vtx[gen & 1].kd_slot[v].w);
         unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
         if (record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) >= shadow_base + W.shadow_shard_entries) have = 0;
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
@@ -821,13 +821,13 @@ __global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen,
         for (int kl = 0; kl < k_pad; ++kl) {
             if (!((have >> kl) & 1ull)) continue;
             const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
-            const float4 fd = W.shadow.fd_ray[ri];
+            const float4 fd = W.shadow[gen & 1].fd_ray[ri];
             if (__float_as_uint(fd.w) != ray) {
                 ray = __float_as_uint(fd.w);
-                vis = W.shadow.vis[ray];
+                vis = W.shadow[gen & 1].vis[ray];
             }
             if (vis == 0.f) continue;
-            const float4 fs = W.shadow.fs_[ri];
+            const float4 fs = W.shadow[gen & 1].fs_[ri];
             c = add(c, mk(fd.x, fd.y, fd.z));
             c = add(c, mk(fs.x, fs.y, fs.z));
         }
@@ -932,8 +932,10 @@ struct rt_scene {
     size_t framebuffer_floats = 0;
     bool counters = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // generate, closest-hit trace, shade, resolve
+    hipStream_t stream2 = nullptr;   // direct lighting (light setup, any-hit trace, gather)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> shaded, lit;   // per generation: shade done (stream) / direct lighting done (stream2)
     // wavefront state (allocated on first render, kept)
     Wavefront wf{};
     std::vector<void *> wf_allocations;
@@ -958,8 +960,9 @@ struct rt_scene {
 // Times one kernel launch when profiling is on: records an event before and (on destruction) after it.
 struct LaunchTimer {
     rt_scene *s;
+    hipStream_t stream;
     hipEvent_t end = nullptr;
-    LaunchTimer(rt_scene *scene, int kernel) : s(scene) {
+    LaunchTimer(rt_scene *scene, int kernel, hipStream_t on) : s(scene), stream(on) {
         if (!s->profiling) return;
         while (s->event_pool.size() < s->events_used + 2) {
             hipEvent_t e;
@@ -968,11 +971,11 @@ struct LaunchTimer {
         }
         hipEvent_t begin = s->event_pool[s->events_used++];
         end = s->event_pool[s->events_used++];
-        (void)hipEventRecord(begin, s->stream);
+        (void)hipEventRecord(begin, stream);
         s->brackets.push_back({kernel, begin, end});
     }
     ~LaunchTimer() {
-        if (end) (void)hipEventRecord(end, s->stream);
+        if (end) (void)hipEventRecord(end, stream);
     }
 };
 
@@ -994,62 +997,81 @@ static void harvest_timers(rt_scene *s) {
 constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
 
 // Upper bound of entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides).  One
-// entry costs ~1.26 KB of HBM, most of it the 16 shadow records; the default of 64 Mi entries is 85 GB of the
-// 288 GB.  Large batches matter: every kernel of a batch ends with a tail in which the last rays finish on a mostly
-// idle chip, and the fewer batches a frame has, the fewer tails it pays for.
+// entry costs ~2.5 KB of HBM, most of it the two sets of 16 shadow records; the default of 48 Mi entries is 121 GB
+// of the 288 GB.  Large batches matter: every kernel of a batch ends with a tail in which the last rays finish on a
+// mostly idle chip, and the fewer batches a frame has, the fewer tails it pays for.
 static unsigned wavefront_capacity() {
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
         if (v >= 65536 && v <= (1l << 27)) return (unsigned)v / (N_SHARDS * 256) * (N_SHARDS * 256);
     }
-    return 1u << 26;
+    return 3u << 24;
 }
 
-// Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries; grows, never shrinks.
-static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
-    // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
-    const unsigned long long unit = N_SHARDS * 256;
-    wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
-    const unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity());
-    if (s->wf.capacity >= cap) return 0;
-    HIP_OK(hipStreamSynchronize(s->stream));
-    for (void *p : s->wf_allocations) (void)hipFree(p);
-    s->wf_allocations.clear();
-    s->wf = Wavefront{};
-    Wavefront W{};
-    auto alloc = [&](void **p, size_t bytes) -> int {
-        HIP_OK(hipMalloc(p, bytes));
+// Allocates the wavefront state for `cap` entries; on failure everything allocated so far is released.
+static int allocate_wavefront(rt_scene *s, unsigned cap, Wavefront &W) {
+    auto alloc = [&](void **p, size_t bytes) -> bool {
+        if (hipMalloc(p, bytes) != hipSuccess) return false;
         s->wf_allocations.push_back(*p);
-        return 0;
+        return true;
     };
-    for (int k = 0; k < 2; ++k) {
-        if (alloc((void **)&W.q[k].o_time, (size_t)cap * 16) || alloc((void **)&W.q[k].d_key, (size_t)cap * 16) ||
-            alloc((void **)&W.q[k].thr_slot, (size_t)cap * 16) || alloc((void **)&W.q[k].depth_flags, (size_t)cap * 4))
-            return 10;
-    }
-    if (alloc((void **)&W.hit_t, (size_t)cap * 4) || alloc((void **)&W.hit_prim, (size_t)cap * 4) ||
-        alloc((void **)&W.vtx.p_time, (size_t)cap * 16) || alloc((void **)&W.vtx.n_key, (size_t)cap * 16) ||
-        alloc((void **)&W.vtx.view_mat, (size_t)cap * 16) || alloc((void **)&W.vtx.kd_slot, (size_t)cap * 16) ||
-        alloc((void **)&W.vtx.ks_n, (size_t)cap * 16) || alloc((void **)&W.vtx.weight, (size_t)cap * 16) ||
-        alloc((void **)&W.vtx.amb_first, (size_t)cap * 16) || alloc((void **)&W.accum, (size_t)cap * 12) ||
-        alloc((void **)&W.counters, COUNTER_WORDS * sizeof(unsigned)))
-        return 10;
     const size_t scap = (size_t)cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
-    if (alloc((void **)&W.shadow.o_dist, scap * 16) || alloc((void **)&W.shadow.d_time, scap * 16) ||
-        alloc((void **)&W.shadow.fd_ray, scap * 16) || alloc((void **)&W.shadow.fs_, scap * 16) || alloc((void **)&W.shadow.vis, scap * 4))
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; ++k) {
+        ok = alloc((void **)&W.q[k].o_time, (size_t)cap * 16) && alloc((void **)&W.q[k].d_key, (size_t)cap * 16) &&
+             alloc((void **)&W.q[k].thr_slot, (size_t)cap * 16) && alloc((void **)&W.q[k].depth_flags, (size_t)cap * 4) &&
+             alloc((void **)&W.vtx[k].p_time, (size_t)cap * 16) && alloc((void **)&W.vtx[k].n_key, (size_t)cap * 16) &&
+             alloc((void **)&W.vtx[k].view_mat, (size_t)cap * 16) && alloc((void **)&W.vtx[k].kd_slot, (size_t)cap * 16) &&
+             alloc((void **)&W.vtx[k].ks_n, (size_t)cap * 16) && alloc((void **)&W.vtx[k].weight, (size_t)cap * 16) &&
+             alloc((void **)&W.vtx[k].amb_first, (size_t)cap * 16) && alloc((void **)&W.shadow[k].o_dist, scap * 16) &&
+             alloc((void **)&W.shadow[k].d_time, scap * 16) && alloc((void **)&W.shadow[k].fd_ray, scap * 16) &&
+             alloc((void **)&W.shadow[k].fs_, scap * 16) && alloc((void **)&W.shadow[k].vis, scap * 4);
+    }
+    ok = ok && alloc((void **)&W.hit_t, (size_t)cap * 4) && alloc((void **)&W.hit_prim, (size_t)cap * 4) &&
+         alloc((void **)&W.accum, (size_t)cap * 12) && alloc((void **)&W.counters, COUNTER_WORDS * sizeof(unsigned));
+    if (!ok) {
+        for (void *p : s->wf_allocations) (void)hipFree(p);
+        s->wf_allocations.clear();
+        (void)hipGetLastError();
         return 10;
+    }
     W.shadow_shard_entries = (unsigned)(scap / N_SHARDS);
     W.overflow = W.counters + COUNTER_WORDS - 1;
     W.shard_entries = cap / N_SHARDS;
     W.capacity = cap;
-    if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
-    s->wf = W;
     return 0;
+}
+
+// Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries; grows, never shrinks.  When
+// the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
+static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
+    // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
+    const unsigned long long unit = N_SHARDS * 256;
+    wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
+    unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity());
+    if (s->wf.capacity >= cap) return 0;
+    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream2));
+    for (void *p : s->wf_allocations) (void)hipFree(p);
+    s->wf_allocations.clear();
+    s->wf = Wavefront{};
+    if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
+    for (;;) {
+        Wavefront W{};
+        if (allocate_wavefront(s, cap, W) == 0) {
+            s->wf = W;
+            return 0;
+        }
+        if (cap <= (1u << 20)) break;
+        cap = (unsigned)((cap / 2 + unit - 1) / unit * unit);
+    }
+    g_error = "cannot allocate the wavefront state (lower RT_WAVEFRONT_CAPACITY)";
+    return 10;
 }
 
 // Launches the persistent trace kernel: as many workgroups as stay resident at once, never more than `grid_limit`
 // (the grid a one-ray-per-lane launch would use; small batches need fewer workgroups than the chip holds).
-static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, int whitted) {
+static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned grid_limit, int gen, int whitted) {
     const bool count = s->counters;
     unsigned &blocks = s->trace_blocks[any][count];
     if (!blocks) {
@@ -1062,7 +1084,7 @@ static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, in
         blocks = std::max(1u, (unsigned)per_cu * (unsigned)cus / N_SHARDS) * N_SHARDS;
     }
     const dim3 grid(std::min(blocks, std::max(grid_limit, (unsigned)N_SHARDS)));
-    LaunchTimer timer(s, any ? RT_KERNEL_TRACE_ANY : RT_KERNEL_TRACE_CLOSEST);
+    LaunchTimer timer(s, any ? RT_KERNEL_TRACE_ANY : RT_KERNEL_TRACE_CLOSEST, stream);
     static const TraceTuning tune = [] {
         TraceTuning t{16, 16};
         if (const char *e = getenv("RT_TRACE_REFILL_MIN")) t.refill_min = std::min(64, std::max(1, atoi(e)));
@@ -1071,14 +1093,14 @@ static void launch_trace(rt_scene *s, bool any, unsigned grid_limit, int gen, in
     }();
     if (any) {
         if (count)
-            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
+            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
         else
-            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
+            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
     } else {
         if (count)
-            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
+            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
         else
-            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, s->stream, s->dev, s->wf, gen, whitted, tune, s->stats);
+            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
     }
 }
 
@@ -1307,6 +1329,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     D.bg_tex = d->background_texture;
     D.is_probe = d->is_probe;
     if (hipMalloc((void **)&s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+        hipStreamCreate(&s->stream2) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         g_error = "rt_scene_create: cannot allocate stream/events";
         rt_scene_destroy(s);
@@ -1338,6 +1361,9 @@ void rt_scene_destroy(rt_scene *s) {
     if (s->stats) (void)hipFree(s->stats);
     if (s->framebuffer) (void)hipFree(s->framebuffer);
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->shaded) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->lit) (void)hipEventDestroy(e);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1465,6 +1491,13 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     HIP_OK(hipEventRecord(s->ev0, s->stream));
 
     const int n_gen = (int)ceilf(s->dev.max_depth) + 1;   // path depths 0 .. ceil(MaxRecursionDepth)
+    while ((int)s->shaded.size() < n_gen) {
+        hipEvent_t a, b;
+        HIP_OK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        s->shaded.push_back(a);
+        HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        s->lit.push_back(b);
+    }
     // Identical shadow rays of a vertex are traced once.  With the work counters on, every light sample's ray is
     // traced on its own so that the counts are those of the reference's loop (src/ray_trace.cpp:182-241).
     const char *share_env = getenv("RT_SHARE_SHADOW_RAYS");   // "0" traces every sample's ray (for A/B measurements)
@@ -1490,41 +1523,49 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
         HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
         {
-            LaunchTimer timer(s, RT_KERNEL_GENERATE);
+            LaunchTimer timer(s, RT_KERNEL_GENERATE, s->stream);
             hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
         }
         // consumer grids: a whole number of workgroups per shard
         const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
         const unsigned grid = per_shard * N_SHARDS;
+        // Two streams: `stream` walks the paths (closest hit, shade), `stream2` lights the vertices of a generation
+        // while `stream` already traces the next one, so that the tail of one kernel is filled by the other chain.
+        // Vertex and shadow buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
         for (int gen = 0; gen < n_gen; ++gen) {
-            launch_trace(s, false, grid, gen, pt ? 0 : 1);
+            launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
+            if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));
             {
-                LaunchTimer timer(s, RT_KERNEL_SHADE);
+                LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
                 if (pt)
                     hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
                 else
                     hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
             }
+            HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
+            HIP_OK(hipStreamWaitEvent(s->stream2, s->shaded[gen], 0));
             const int n_pass = (s->k_total + 63) / 64;
             for (int pass = 0; pass < n_pass; ++pass) {
                 if (pass > 0)
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
-                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream));
+                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream2));
                 {
-                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP);
-                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, s->stream2);
+                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream2, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
                 }
-                launch_trace(s, true, grid, gen, 0);
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, pass, s->k_pad, 1);
+                launch_trace(s, s->stream2, true, grid, gen, 0);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, s->stream2);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream2, W, gen, pass, s->k_pad, 1);
             }
             if (n_pass == 0 && !pt) {   // ambient only
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream, W, gen, 0, 1, 0);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, s->stream2);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream2, W, gen, 0, 1, 0);
             }
+            HIP_OK(hipEventRecord(s->lit[gen], s->stream2));
         }
+        for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
         {
-            LaunchTimer timer(s, RT_KERNEL_RESOLVE);
+            LaunchTimer timer(s, RT_KERNEL_RESOLVE, s->stream);
             hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
         }
         HIP_OK(hipGetLastError());
@@ -1613,7 +1654,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
         HIP_OK(hipMemsetAsync(W.counters, 0, (COUNTER_WORDS - 1) * sizeof(unsigned), s->stream));   // all but the overflow flag
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
         const unsigned grid = std::min(4096u / N_SHARDS, std::max(1u, (slots / N_SHARDS + 255) / 256)) * N_SHARDS;
-        launch_trace(s, false, grid, 0, 0);
+        launch_trace(s, s->stream, false, grid, 0, 0);
         hipLaunchKernelGGL(primary_out_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, d_shape, d_id, d_t);
         HIP_OK(hipGetLastError());
     }
