@@ -99,6 +99,25 @@ def kernel_bytes(st):
     }
 
 
+PMC_KERNEL_NAMES = {"generate": "generate_kernel", "trace_closest": "trace_kernel<false, false>", "shade": "shade_kernel<true>",
+                    "light_setup": "light_setup_kernel", "light_gather": "light_gather_kernel", "resolve": "resolve_kernel"}
+
+
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 counter passes over this benchmark
+    (tools/pmc_traffic_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, reads doubled as gfx950 requires).
+    None when there is no pass for this workload or kernel (a counter pass cannot run inside the timed program)."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_bench.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if doc.get("workload") != workload or kernel not in PMC_KERNEL_NAMES:
+        return None
+    entry = doc.get("kernels", {}).get(PMC_KERNEL_NAMES[kernel])
+    return entry.get("traffic_bytes_per_launch") if entry else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +195,11 @@ def main():
     unshared_ms = None
     if world == 1:
         os.environ["RT_SHARE_SHADOW_RAYS"] = "0"
-        _, us = ren.render(cam, out=fb.data_ptr())
-        unshared_ms = us.total_ms
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ren.render(cam, out=fb.data_ptr())
+        torch.cuda.synchronize()
+        unshared_ms = (time.perf_counter() - t1) * 1e3
         del os.environ["RT_SHARE_SHADOW_RAYS"]
 
     t = torch.tensor([elapsed, float(rays), float(traced)], dtype=torch.float64, device="cuda")
@@ -213,7 +235,7 @@ def main():
             "rays_per_frame": rays / args.steps, "traversals_per_frame": traced / args.steps,
             "value_traversals": traced / elapsed / 1e6,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, name) if world == 1 else None,
                          "kernel_ms_per_launch": ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches_per_frame": launches_per_frame,
                          "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()}},
