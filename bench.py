@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "pt1m_4k_256spp"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device rehearses the multi-rank path on a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -140,10 +143,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering core has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     scene_dir = os.path.join(tempfile.gettempdir(), f"rt_bench_scenes_{os.getuid()}_{rank}")
@@ -202,7 +210,7 @@ def main():
         unshared_ms = (time.perf_counter() - t1) * 1e3
         del os.environ["RT_SHARE_SHADOW_RAYS"]
 
-    t = torch.tensor([elapsed, float(rays), float(traced)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed, float(rays), float(traced)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -31,5 +31,11 @@ def gather_frame(fb, world):
     """Collects the ranks' disjoint tiles on rank 0, in place; `fb` is a torch tensor (any device)."""
     if world > 1:
         import torch.distributed as dist
-        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        if fb.is_cuda and dist.get_backend() == "gloo":   # rehearsals without RCCL: stage through host memory
+            host = fb.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if dist.get_rank() == 0:
+                fb.copy_(host)
+        else:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
     return fb
