@@ -1,0 +1,119 @@
+"""GPU edge cases through the C ABI: empty and ragged inputs, non-square sample counts, tiny queues that force
+several batches and the overflow retry, and rejected descriptions.  Results are checked against the CPU oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as R
+from raytracer_amd import _abi as A
+from golden import scenes as GS
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def patched(src, dst, edit):
+    doc = json.load(open(src))
+    edit(doc["Scene"])
+    with open(dst, "w") as f:
+        json.dump(doc, f)
+    return dst
+
+
+def same_as_oracle(path, tol=2e-4, **cam_overrides):
+    sc = R.Scene(path)
+    cam = sc.camera(0, **cam_overrides)
+    ren = R.Renderer(sc)
+    ren.set_counters(True)
+    gpu, sg = ren.render(cam)
+    cpu, so = Oracle(sc).render(cam)
+    assert (sg.primary_rays, sg.shadow_rays, sg.secondary_rays) == (so.primary_rays, so.shadow_rays, so.secondary_rays)
+    assert (sg.nodes_visited, sg.triangle_tests, sg.sphere_tests) == (so.nodes_visited, so.triangle_tests, so.sphere_tests)
+    err = np.abs(gpu - cpu) / np.maximum(np.abs(cpu), 1 / 255)
+    assert (err > tol).mean() <= 2e-3, err.max()
+    return gpu, sg
+
+
+def test_scene_without_objects_is_background(tmp_path):
+    def edit(s):
+        s["Objects"] = {}
+        s["BackgroundColor"] = "10 20 30"
+    path = patched(os.path.join(ROOT, "scenes", "simple.json"), str(tmp_path / "empty.json"), edit)
+    img, st = same_as_oracle(path)
+    assert st.shadow_rays == 0 and st.secondary_rays == 0 and st.nodes_visited == 0
+    assert np.unique(img.reshape(-1, 3), axis=0).shape[0] == 1
+
+
+def test_scene_without_lights(tmp_path):
+    def edit(s):
+        s["Lights"] = {"AmbientLight": "25 25 25"}
+    same_as_oracle(patched(os.path.join(ROOT, "scenes", "simple.json"), str(tmp_path / "nolights.json"), edit))
+
+
+@pytest.mark.parametrize("res", [(1, 1), (33, 31), (31, 65), (100, 7)])
+def test_ragged_resolutions(res):
+    """Frames that do not fill their last 32x32 tiles, down to a single pixel."""
+    img, st = same_as_oracle(os.path.join(ROOT, "scenes", "simple.json"), resx=res[0], resy=res[1])
+    assert img.shape == (res[1], res[0], 3) and st.primary_rays == res[0] * res[1]
+
+
+def test_sample_count_that_is_not_a_square(scene_dir):
+    """NumSamples 10 renders floor(sqrt(10))^2 = 9 samples (src/camera.cpp:149)."""
+    path = GS.SCENES["distributed"][0](scene_dir)
+    sc = R.Scene(path)
+    cam = sc.camera(0, num_samples=10)
+    img, st = same_as_oracle(path, num_samples=10)
+    assert st.primary_rays == cam.resx * cam.resy * 9
+
+
+@pytest.mark.parametrize("name", ["materials", "pathtrace", "distributed"])
+def test_small_queues_force_batches_and_retries(name, scene_dir, monkeypatch):
+    """With a small wavefront (256 Ki entries; one tile of a 64-sample camera needs 64 Ki, times its branching) a
+    frame needs several batches, and scenes whose paths branch more than planned are retried.  The image must not
+    depend on any of that."""
+    path = GS.SCENES[name][0](scene_dir)
+    sc = R.Scene(path)
+    cam = sc.camera(0)
+    big, sb = R.Renderer(sc).render(cam)
+    monkeypatch.setenv("RT_WAVEFRONT_CAPACITY", "262144")
+    small, ss = R.Renderer(sc).render(cam)
+    assert ss.total_rays == sb.total_rays
+    err = np.abs(small - big) / np.maximum(np.abs(big), 1 / 255)
+    assert err.max() <= 1e-5
+
+
+def test_rejected_descriptions():
+    g = R.gpu_lib()
+    sc = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
+    ptr = C.c_void_p()
+    # wrong ABI version
+    desc = A.SceneDesc.from_buffer_copy(sc.desc)
+    desc.abi_version = 1
+    assert g.rt_scene_create(C.byref(desc), C.byref(ptr)) != 0 and b"ABI" in g.rt_last_error()
+    # a BVH node that points outside the node array
+    desc = A.SceneDesc.from_buffer_copy(sc.desc)
+    nodes = (A.BvhNode * desc.n_bvh_nodes)()
+    C.memmove(nodes, desc.bvh_nodes, C.sizeof(nodes))
+    interior = [i for i in range(desc.n_bvh_nodes) if nodes[i].n_prims == 0]
+    assert interior
+    nodes[interior[0]].offset = desc.n_bvh_nodes + 5
+    desc.bvh_nodes = C.cast(nodes, C.POINTER(A.BvhNode))
+    assert g.rt_scene_create(C.byref(desc), C.byref(ptr)) != 0 and b"BVH" in g.rt_last_error()
+    # a leaf entry that names a triangle that does not exist
+    desc = A.SceneDesc.from_buffer_copy(sc.desc)
+    prims = (A.BvhPrim * desc.n_bvh_prims)()
+    C.memmove(prims, desc.bvh_prims, C.sizeof(prims))
+    prims[0].shape = desc.n_triangles + desc.n_spheres
+    desc.bvh_prims = C.cast(prims, C.POINTER(A.BvhPrim))
+    assert g.rt_scene_create(C.byref(desc), C.byref(ptr)) != 0
+    # camera and argument checks
+    ren = R.Renderer(sc)
+    with pytest.raises(R.RaytracerError):
+        ren.render(sc.camera(0, resx=0), out=np.zeros((1, 1, 3), dtype=np.float32))
+    with pytest.raises(R.RaytracerError):
+        ren.render(sc.camera(0), out=np.zeros((64, 64, 3), dtype=np.float32), rank=2, world=2)
+    assert g.rt_render(None, None, None, None) != 0
