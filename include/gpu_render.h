@@ -295,6 +295,21 @@ void rt_scene_destroy(rt_scene *scene);
  * arithmetic is bit-identical to a strict IEEE-754 evaluation on the host. */
 int rt_selftest_math(int32_t fn, int32_t n, const float *a, const float *b, float *out);
 
+/* Tone mapping of a finished frame on the device: apply_tonemap (src/main.cpp:267-345) -- log-average luminance,
+ * exposure opt1 / average, burn-percent (opt2) white point as an exact order statistic, photographic / filmic /
+ * ACES curve, saturation (+0.2 bias) and gamma (0 = 2.2) -- into 8-bit RGB in the same pixel order.  hdr and
+ * rgb8_out may each be host or device memory; with both on the device the frame never crosses PCIe as floats. */
+typedef struct rt_tonemap_desc {
+    int32_t tmo;         /* RT_TMO_* */
+    float opt1, opt2;    /* TMOOptions: key value, burn percent */
+    float saturation;
+    float gamma;
+} rt_tonemap_desc;
+int rt_tonemap(const float *hdr, int32_t width, int32_t height, const rt_tonemap_desc *tm, uint8_t *rgb8_out);
+
+/* The reference's plain LDR conversion, (unsigned char)clamp(v * 255, 0, 255) (src/main.cpp:579-583), on the device. */
+int rt_quantize_ldr(const float *hdr, int64_t n_values, uint8_t *out);
+
 /* Message of the last failing call on this thread ("" if none).  The reference's convention is
  * print + exit(code) (src/main.cpp:544,654; src/parser.cpp:855); the ABI returns nonzero instead. */
 const char *rt_last_error(void);

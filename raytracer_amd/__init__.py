@@ -71,6 +71,8 @@ def gpu_lib():
                                        C.POINTER(A.Stats)]
         g.rt_shard_owner_map.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         g.rt_set_counters.argtypes = [C.c_void_p, C.c_int32]
+        g.rt_tonemap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(A.TonemapDesc), C.c_void_p]
+        g.rt_quantize_ldr.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         g.rt_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         g.rt_kernel_times.argtypes = [C.c_void_p, C.POINTER(A.KernelTime)]
         g.rt_scene_destroy.argtypes = [C.c_void_p]
@@ -203,6 +205,26 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def gpu_tonemap(hdr, tmo, opt1, opt2, saturation, gamma):
+    """rt_tonemap on a host array (H, W, 3) float32 -> uint8 array of the same shape."""
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.empty(hdr.shape, dtype=np.uint8)
+    desc = A.TonemapDesc(int(tmo), float(opt1), float(opt2), float(saturation), float(gamma))
+    g = gpu_lib()
+    if g.rt_tonemap(hdr.ctypes.data, hdr.shape[1], hdr.shape[0], C.byref(desc), out.ctypes.data) != 0:
+        raise RaytracerError("rt_tonemap: " + g.rt_last_error().decode())
+    return out
+
+
+def gpu_quantize_ldr(hdr):
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    out = np.empty(hdr.shape, dtype=np.uint8)
+    g = gpu_lib()
+    if g.rt_quantize_ldr(hdr.ctypes.data, hdr.size, out.ctypes.data) != 0:
+        raise RaytracerError("rt_quantize_ldr: " + g.rt_last_error().decode())
+    return out
 
 
 def write_outputs(scene, camera_index, hdr, out_dir="outputs"):

@@ -122,3 +122,7 @@ KERNEL_NAMES = ["generate", "trace_closest", "shade", "light_setup", "trace_any"
 
 class KernelTime(C.Structure):
     _fields_ = [("launches", u64), ("total_ms", C.c_double)]
+
+
+class TonemapDesc(C.Structure):
+    _fields_ = [("tmo", i32), ("opt1", f32), ("opt2", f32), ("saturation", f32), ("gamma", f32)]

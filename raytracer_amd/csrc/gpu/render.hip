@@ -6,12 +6,12 @@
 // tests src/shapes.cpp:212,407,506, calculate_color src/ray_trace.cpp:154-406, Light::get_sample
 // src/lights.cpp, texture::sample src/texture.cpp:168-197).
 //
-// Execution shape: one lane per pixel, 8x8 pixel sub-tiles per wave, 16x16 per workgroup, workgroups
-// enumerated over 32x32 image tiles (the reference's square_dynamic tile, src/main.cpp:441) so that a
-// frame can be sharded by tile over ranks.  A lane walks its pixel's samples in order and, per
-// sample, its path tree depth-first through a small explicit stack of pending rays carrying their
-// throughput (the reference's recursion, flattened).  Results of a pixel therefore do not depend on
-// launch geometry, sharding or scheduling, and sample sums are taken in the reference's order.
+// Execution shape: a wavefront pipeline.  A frame is rendered in batches of camera samples; per batch the paths
+// advance one generation at a time through generate -> trace (closest hit) -> shade, and the vertices of a
+// generation are lit by light_setup -> trace (any hit) -> light_gather on a second stream.  Queues are compacted
+// with wave ballots and split into 64 shards; frames shard over ranks by 32x32 image tiles (the reference's
+// square_dynamic tile, src/main.cpp:441).  A slot's random numbers depend only on (seed, pixel, sample, path node),
+// so results do not depend on launch geometry, batching, sharding or scheduling.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1697,3 +1697,5 @@ int rt_selftest_math(int32_t fn, int32_t n, const float *a, const float *b, floa
 }
 
 }  // extern "C"
+
+#include "rt_tonemap.h"

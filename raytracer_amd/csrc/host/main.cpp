@@ -110,9 +110,24 @@ static int process_file(const char *filename, int thread_count, int threading_ty
         log_printf("%s started\n", cam.image_name.c_str());
         start = std::chrono::high_resolution_clock::now();
         const int W = cam.desc.resx, H = cam.desc.resy;
-        std::vector<float> hdr((size_t)W * H * 3, 0.0f);
+        const std::string &name = cam.image_name;
+        const bool exr = cam.desc.is_hdr || (name.size() >= 4 && name.compare(name.size() - 4, 4, ".exr") == 0);
+        // Only an EXR needs the float frame on the host; for PNG outputs the frame stays in HBM and is tone-mapped
+        // or quantised there (rt_tonemap / rt_quantize_ldr), so 8-bit pixels are all that crosses PCIe.
+        std::vector<float> hdr;
+        float *frame = nullptr, *device_frame = nullptr;
+        if (exr) {
+            hdr.assign((size_t)W * H * 3, 0.0f);
+            frame = hdr.data();
+        } else {
+            if (hipMalloc((void **)&device_frame, (size_t)W * H * 3 * sizeof(float)) != hipSuccess) {
+                log_printf("cannot allocate the device framebuffer\n");
+                exit(-1);
+            }
+            frame = device_frame;
+        }
         rt_stats stats;
-        if (rt_render(gpu, &cam.desc, hdr.data(), &stats) != 0) {
+        if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
             log_printf("rt_render failed: %s\n", rt_last_error());
             exit(-1);
         }
@@ -123,20 +138,26 @@ static int process_file(const char *filename, int thread_count, int threading_ty
                    (unsigned long long)stats.primary_rays, (unsigned long long)stats.shadow_rays, (unsigned long long)stats.secondary_rays,
                    stats.kernel_ms, stats.kernel_ms > 0 ? rays / stats.kernel_ms / 1e3 : 0.0);
 
-        const std::string &name = cam.image_name;
-        const bool exr = cam.desc.is_hdr || (name.size() >= 4 && name.compare(name.size() - 4, 4, ".exr") == 0);
+        const size_t n_values = (size_t)W * H * 3;
         if (exr) {
             log_printf("%s write EXR started\n", name.c_str());
             if (!rth::write_exr_rgb32f("outputs/" + name, W, H, hdr.data())) fprintf(stderr, "Save EXR Error: cannot write outputs/%s\n", name.c_str());
         } else if (cam.tonemaps.empty()) {
-            std::vector<uint8_t> ldr(hdr.size());
-            rth_quantize_ldr((int64_t)hdr.size(), hdr.data(), ldr.data());
+            std::vector<uint8_t> ldr(n_values);
+            if (rt_quantize_ldr(frame, (int64_t)n_values, ldr.data()) != 0) {
+                log_printf("rt_quantize_ldr failed: %s\n", rt_last_error());
+                exit(-1);
+            }
             rth::write_png_rgb8("outputs/" + name, W, H, ldr.data(), true);
         }
         if (!cam.tonemaps.empty()) {
-            std::vector<uint8_t> tm_out(hdr.size());
+            std::vector<uint8_t> tm_out(n_values);
             for (auto &tm : cam.tonemaps) {
-                rth::apply_tonemap(tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma, W, H, hdr.data(), tm_out.data());
+                const rt_tonemap_desc td{tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma};
+                if (rt_tonemap(frame, W, H, &td, tm_out.data()) != 0) {
+                    log_printf("rt_tonemap failed: %s\n", rt_last_error());
+                    exit(-1);
+                }
                 std::string base = name;
                 size_t dot = base.find_last_of('.');
                 if (dot != std::string::npos) base = base.substr(0, dot);
@@ -145,6 +166,7 @@ static int process_file(const char *filename, int thread_count, int threading_ty
                 rth::write_png_rgb8("outputs/" + tm_name, W, H, tm_out.data(), true);
             }
         }
+        if (device_frame) (void)hipFree(device_frame);
     }
     rt_scene_destroy(gpu);
     return 0;

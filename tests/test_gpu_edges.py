@@ -117,3 +117,38 @@ def test_rejected_descriptions():
     with pytest.raises(R.RaytracerError):
         ren.render(sc.camera(0), out=np.zeros((64, 64, 3), dtype=np.float32), rank=2, world=2)
     assert g.rt_render(None, None, None, None) != 0
+
+
+def test_command_line_end_to_end(tmp_path, scene_dir):
+    """./raytracer on a PNG scene and on an EXR scene with tone maps: the files the reference would write, with the
+    pixels of a render through the ABI."""
+    import ctypes
+    import subprocess
+    from test_host import png_pixels
+    exe = os.path.join(ROOT, "raytracer")
+    simple = os.path.join(ROOT, "scenes", "simple.json")
+    r = subprocess.run([exe, simple], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "simple.png rendering done:" in r.stdout
+    sc = R.Scene(simple)
+    img, _ = R.Renderer(sc).render(sc.camera(0))
+    assert np.array_equal(png_pixels(str(tmp_path / "outputs" / "simple.png")), R.gpu_quantize_ldr(img)[::-1])
+
+    def edit(s):
+        s["Cameras"]["Camera"]["Tonemap"] = [
+            {"TMO": "Photographic", "TMOOptions": "0.18 2", "Saturation": "1.0", "Gamma": "2.2", "Extension": "_phot.png"},
+            {"TMO": "ACES", "TMOOptions": "0.5 0", "Saturation": "1.0", "Gamma": "1.8", "Extension": "_aces.png"}]
+    env = patched(GS.SCENES["envmap"][0](scene_dir), os.path.join(scene_dir, "envmap_tm.json"), edit)
+    r = subprocess.run([exe, env, "0", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Saving tone mapped image: envmap_phot.png" in r.stdout
+    h = R.host_lib()
+    w_, h_ = ctypes.c_int32(), ctypes.c_int32()
+    exr = os.fsencode(str(tmp_path / "outputs" / "envmap.exr"))
+    assert h.rth_read_exr(exr, ctypes.byref(w_), ctypes.byref(h_), None) == 0
+    rgba = np.empty((h_.value, w_.value, 4), dtype=np.float32)
+    assert h.rth_read_exr(exr, ctypes.byref(w_), ctypes.byref(h_), rgba.ctypes.data) == 0
+    frame = np.ascontiguousarray(rgba[:, :, :3])
+    assert np.isfinite(frame).all() and frame.max() > 0
+    assert np.array_equal(png_pixels(str(tmp_path / "outputs" / "envmap_phot.png")), R.gpu_tonemap(frame, 0, 0.18, 2.0, 1.0, 2.2)[::-1])
+    assert np.array_equal(png_pixels(str(tmp_path / "outputs" / "envmap_aces.png")), R.gpu_tonemap(frame, 2, 0.5, 0.0, 1.0, 1.8)[::-1])
