@@ -240,6 +240,10 @@ def main():
                        "renderer": "path tracing" if cam.path_tracing else "whitted", "sharding": f"tiles32/{world}"},
             # rays as the reference's algorithm casts them (the unit the CPU baseline is counted in) and the
             # traversals actually run: light samples of a shading point with bit-identical shadow rays share one
+            "ray_accounting": "rays as the reference's algorithm casts them (oracle counters), the unit of cpu_baseline; "
+                              "light samples of a shading point with bit-identical shadow rays share one traversal: "
+                              "traversals_per_frame / value_traversals count traversals run, without_ray_sharing times "
+                              "a frame with sharing off",
             "rays_per_frame": rays / args.steps, "traversals_per_frame": traced / args.steps,
             "value_traversals": traced / elapsed / 1e6,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
