@@ -1,0 +1,47 @@
+"""The HIP rendering core directly against the fixtures produced by the compiled reference (tests/golden/*.npz),
+with the same bars the CPU oracle has to meet in test_oracle_vs_reference.py: primary-hit identities, hit distances
+and deterministic images of the reference itself; stochastic scenes statistically (the reference's random numbers
+cannot be seeded)."""
+import numpy as np
+import pytest
+
+import raytracer_amd as R
+from golden import scenes as S
+from test_oracle_vs_reference import EXACT, STOCHASTIC, load, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", EXACT)
+def test_exact_scene_against_reference(name, scene_dir, repo_root):
+    g = load(name)
+    sc = R.Scene(scene_path(name, scene_dir, repo_root))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    shape, ids, t, _ = ren.trace_primary(cam)
+    ref_ids, ref_t = g["ids"], g["t"]
+    mismatch = (shape != ref_ids[:, 0]) | (ids != ref_ids[:, 1])
+    assert mismatch.mean() <= max(1e-4, 1.5 / len(shape)), f"{mismatch.sum()} of {len(shape)} primary-hit ids differ"
+    both = (shape >= 0) & (ref_ids[:, 0] >= 0) & ~mismatch
+    assert np.mean(np.abs(t[both] - ref_t[both]) > 2e-4 * np.maximum(1.0, ref_t[both])) <= 1e-3
+    img, _ = ren.render(cam)
+    err = (np.abs(img - g["hdr"]) / np.maximum(np.abs(g["hdr"]), 1.0 / 255.0)).max(axis=2)
+    assert (err > 2e-3).mean() <= 1e-3, f"{(err > 2e-3).sum()} pixels differ from the reference image (max {err.max():.3g})"
+
+
+@pytest.mark.parametrize("name", STOCHASTIC)
+def test_stochastic_scene_against_reference(name, scene_dir, repo_root):
+    g = load(name)
+    sc = R.Scene(scene_path(name, scene_dir, repo_root))
+    ren = R.Renderer(sc)
+    reps = 12
+    imgs = np.stack([ren.render(sc.camera(0, seed=2000 + k))[0].astype(np.float64) for k in range(reps)])
+    mean = imgs.mean(axis=0)
+    sem = imgs.std(axis=0, ddof=1) / np.sqrt(reps)
+    ref, ref_sem = g["hdr"].astype(np.float64), g["hdr_std"].astype(np.float64)
+    assert abs(mean.mean() - ref.mean()) <= 0.02 * abs(ref.mean()), (mean.mean(), ref.mean())
+    sigma = np.sqrt(sem ** 2 + ref_sem ** 2) + 1e-3 * np.maximum(np.abs(ref), 1.0 / 255.0)
+    z = np.abs(mean - ref) / sigma
+    off = (z > 6.0) & (np.abs(mean - ref) > 0.05 * np.maximum(np.abs(ref), 1.0 / 255.0))
+    assert np.mean(off) <= 2e-3, f"{np.mean(off):.4f} of values are more than 6 sigma and 5 % from the reference"
+    assert np.median(z) < 1.5
