@@ -7,8 +7,16 @@
 // std::partition / std::nth_element are used exactly where the reference uses them so that the
 // primitive order inside every subtree — and with it the order in which equal-distance hits are
 // found — is the same.
+//
+// The reference builds on one thread.  Here the top of the tree is built on the calling thread and every
+// subtree of at most SUBTREE_ITEMS primitives becomes a task for a pool of threads: a subtree only ever
+// touches its own range of the item array, its leaf offsets are the range's own positions (leaves are
+// emitted in array order), and its node indices are relative until the subtrees are laid out one after
+// the other in pre-order.  The result is the same array, byte for byte, for any number of threads.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "scene.h"
@@ -22,10 +30,17 @@ struct BuildItem {
     float bmin[3], bmax[3], c[3];
 };
 
+constexpr int SUBTREE_ITEMS = 32768;
+
+struct Subtree {
+    int start, end;
+    std::vector<rt_bvh_node> nodes;   // pre-order, child offsets relative to this vector
+};
+
 struct Builder {
-    std::vector<BuildItem> items;
-    std::vector<rt_bvh_node> nodes;
-    std::vector<int> order;   // prim numbers in leaf order
+    BuildItem *items = nullptr;           // shared array; a builder only touches its own range
+    std::vector<rt_bvh_node> nodes;       // pre-order; offset of a deferred subtree's placeholder = -(1 + subtree number)
+    std::vector<Subtree> *deferred = nullptr;   // set on the top-level builder only
 
     static float surface_area(const float *mn, const float *mx) {
         float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
@@ -34,15 +49,20 @@ struct Builder {
     }
 
     void make_leaf(int node, int start, int end) {
-        nodes[node].offset = (int)order.size();
+        nodes[node].offset = start;   // leaves are emitted in array order, so the running count equals `start`
         nodes[node].n_prims = end - start;
         nodes[node].axis = 0;
-        for (int i = start; i < end; ++i) order.push_back(items[i].prim);
     }
 
     int build(int start, int end) {
         const int node = (int)nodes.size();
         nodes.emplace_back();
+        if (deferred && end - start <= SUBTREE_ITEMS && end - start > 1) {   // a task for the pool
+            nodes[node].n_prims = -1;
+            nodes[node].offset = -(1 + (int)deferred->size());
+            deferred->push_back(Subtree{start, end, {}});
+            return node;
+        }
         float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
         for (int i = start; i < end; ++i)
             for (int a = 0; a < 3; ++a) {
@@ -138,12 +158,11 @@ struct Builder {
                 split_bucket = i;
             }
         if (n > 4 || min_cost < (float)n) {
-            auto pmid = std::partition(items.begin() + start, items.begin() + end,
-                                       [=](const BuildItem &it) { return bucket_of(it) <= split_bucket; });
-            int mid = (int)(pmid - items.begin());
+            auto pmid = std::partition(items + start, items + end, [=](const BuildItem &it) { return bucket_of(it) <= split_bucket; });
+            int mid = (int)(pmid - items);
             if (mid == start || mid == end) {
                 mid = start + (end - start) / 2;
-                std::nth_element(items.begin() + start, items.begin() + mid, items.begin() + end,
+                std::nth_element(items + start, items + mid, items + end,
                                  [dim](const BuildItem &a, const BuildItem &b) { return a.c[dim] < b.c[dim]; });
             }
             nodes[node].axis = dim;
@@ -165,21 +184,71 @@ void build_bvh(HostScene &scene) {
     scene.bvh_prims.clear();
     const size_t n = scene.build_prims.size();
     if (n == 0) return;
-    Builder b;
-    b.items.resize(n);
+    std::vector<BuildItem> items(n);
     for (size_t i = 0; i < n; ++i) {
-        BuildItem &it = b.items[i];
+        BuildItem &it = items[i];
         it.prim = (int)i;
         memcpy(it.bmin, scene.build_bounds[i].bmin, 12);
         memcpy(it.bmax, scene.build_bounds[i].bmax, 12);
         for (int a = 0; a < 3; ++a) it.c[a] = (it.bmin[a] + it.bmax[a]) * 0.5f;
     }
-    b.nodes.reserve(2 * n);
-    b.order.reserve(n);
-    b.build(0, (int)n);
-    scene.bvh_nodes = std::move(b.nodes);
+    // top of the tree on this thread; subtrees of <= SUBTREE_ITEMS primitives are deferred
+    std::vector<Subtree> subtrees;
+    Builder top;
+    top.items = items.data();
+    top.deferred = &subtrees;
+    top.build(0, (int)n);
+    // the deferred subtrees on a pool of threads, largest first
+    std::vector<int> by_size(subtrees.size());
+    for (size_t i = 0; i < by_size.size(); ++i) by_size[i] = (int)i;
+    std::sort(by_size.begin(), by_size.end(), [&](int a, int b) {
+        const int sa = subtrees[a].end - subtrees[a].start, sb = subtrees[b].end - subtrees[b].start;
+        return sa != sb ? sa > sb : a < b;
+    });
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= by_size.size()) return;
+            Subtree &st = subtrees[by_size[k]];
+            Builder b;
+            b.items = items.data();
+            b.nodes.reserve(2 * (size_t)(st.end - st.start));
+            b.build(st.start, st.end);
+            st.nodes = std::move(b.nodes);
+        }
+    };
+    unsigned n_threads = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (unsigned)std::min<size_t>(n_threads, std::max<size_t>(1, subtrees.size()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    // lay the pieces out in pre-order: final index of every top node, then copy with the offsets shifted
+    std::vector<int> final_index(top.nodes.size());
+    size_t total = 0;
+    for (size_t i = 0; i < top.nodes.size(); ++i) {
+        final_index[i] = (int)total;
+        total += top.nodes[i].n_prims == -1 ? subtrees[-top.nodes[i].offset - 1].nodes.size() : 1;
+    }
+    scene.bvh_nodes.resize(total);
+    for (size_t i = 0; i < top.nodes.size(); ++i) {
+        const rt_bvh_node &t = top.nodes[i];
+        rt_bvh_node *dst = &scene.bvh_nodes[final_index[i]];
+        if (t.n_prims == -1) {
+            const Subtree &st = subtrees[-t.offset - 1];
+            const int base = final_index[i];
+            for (size_t k = 0; k < st.nodes.size(); ++k) {
+                dst[k] = st.nodes[k];
+                if (dst[k].n_prims == 0) dst[k].offset += base;   // interior: index of the second child
+            }
+        } else {
+            *dst = t;
+            if (t.n_prims == 0) dst->offset = final_index[t.offset];
+        }
+    }
     scene.bvh_prims.resize(n);
-    for (size_t i = 0; i < n; ++i) scene.bvh_prims[i] = scene.build_prims[b.order[i]];
+    for (size_t i = 0; i < n; ++i) scene.bvh_prims[i] = scene.build_prims[items[i].prim];
 }
 
 }  // namespace rth
