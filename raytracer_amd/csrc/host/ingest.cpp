@@ -885,6 +885,8 @@ bool load_scene(const std::string &json_path, HostScene &out, std::string &err) 
         }
 
     // ---- BVH build input: for s in shapes, for id in s->get_ids() (src/bvh.cpp:55-73) ----------
+    out.build_prims.reserve(out.triangles.size() + out.spheres.size());
+    out.build_bounds.reserve(out.triangles.size() + out.spheres.size());
     for (size_t ti = 0; ti < out.triangles.size(); ++ti) {
         const MeshGroup &g = groups[tri_group[ti]];
         for (const auto &kv : g.instance_of) {   // unordered_map iteration order, as triangle::get_ids

@@ -39,16 +39,48 @@ struct Cursor {
     }
 };
 
-bool read_scalar(Cursor &c, const std::string &t, double &v) {
-    if (t == "float" || t == "float32") { float x; if (!c.take(&x, 4)) return false; v = x; return true; }
-    if (t == "double" || t == "float64") { double x; if (!c.take(&x, 8)) return false; v = x; return true; }
-    if (t == "uchar" || t == "uint8") { uint8_t x; if (!c.take(&x, 1)) return false; v = x; return true; }
-    if (t == "char" || t == "int8") { int8_t x; if (!c.take(&x, 1)) return false; v = x; return true; }
-    if (t == "ushort" || t == "uint16") { uint16_t x; if (!c.take(&x, 2)) return false; v = x; return true; }
-    if (t == "short" || t == "int16") { int16_t x; if (!c.take(&x, 2)) return false; v = x; return true; }
-    if (t == "int" || t == "int32" || t == "int32_t") { int32_t x; if (!c.take(&x, 4)) return false; v = x; return true; }
-    if (t == "uint" || t == "uint32" || t == "uint32_t") { uint32_t x; if (!c.take(&x, 4)) return false; v = x; return true; }
-    return false;
+// Scalar types and vertex property names are resolved once, when the header is read (the reference compares
+// strings for every value, src/ply_loader.cpp:185-294).
+enum Scalar { S_UNKNOWN, S_F32, S_F64, S_U8, S_I8, S_U16, S_I16, S_I32, S_U32, S_LIST };
+enum Slot { P_NONE, P_X, P_Y, P_Z, P_NX, P_NY, P_NZ, P_U, P_V };
+
+Scalar scalar_of(const std::string &t) {
+    if (t == "list") return S_LIST;
+    if (t == "float" || t == "float32") return S_F32;
+    if (t == "double" || t == "float64") return S_F64;
+    if (t == "uchar" || t == "uint8") return S_U8;
+    if (t == "char" || t == "int8") return S_I8;
+    if (t == "ushort" || t == "uint16") return S_U16;
+    if (t == "short" || t == "int16") return S_I16;
+    if (t == "int" || t == "int32" || t == "int32_t") return S_I32;
+    if (t == "uint" || t == "uint32" || t == "uint32_t") return S_U32;
+    return S_UNKNOWN;
+}
+
+Slot slot_of(const std::string &name) {
+    if (name == "x") return P_X;
+    if (name == "y") return P_Y;
+    if (name == "z") return P_Z;
+    if (name == "nx") return P_NX;
+    if (name == "ny") return P_NY;
+    if (name == "nz") return P_NZ;
+    if (name == "u" || name == "s") return P_U;
+    if (name == "v" || name == "t") return P_V;
+    return P_NONE;
+}
+
+bool read_scalar(Cursor &c, Scalar t, double &v) {
+    switch (t) {
+        case S_F32: { float x; if (!c.take(&x, 4)) return false; v = x; return true; }
+        case S_F64: { double x; if (!c.take(&x, 8)) return false; v = x; return true; }
+        case S_U8: { uint8_t x; if (!c.take(&x, 1)) return false; v = x; return true; }
+        case S_I8: { int8_t x; if (!c.take(&x, 1)) return false; v = x; return true; }
+        case S_U16: { uint16_t x; if (!c.take(&x, 2)) return false; v = x; return true; }
+        case S_I16: { int16_t x; if (!c.take(&x, 2)) return false; v = x; return true; }
+        case S_I32: { int32_t x; if (!c.take(&x, 4)) return false; v = x; return true; }
+        case S_U32: { uint32_t x; if (!c.take(&x, 4)) return false; v = x; return true; }
+        default: return false;
+    }
 }
 
 }  // namespace
@@ -120,6 +152,11 @@ bool load_ply(const std::string &path, std::vector<float> &vertices, HostScene &
         }
     }
 
+    // per vertex property: (binary scalar type of the lower-cased type name, destination slot)
+    std::vector<std::pair<Scalar, Slot>> vcodes;
+    for (const auto &prop : vprops) vcodes.emplace_back(prop.first == "list" ? S_LIST : scalar_of(lower(prop.first)), slot_of(prop.second));
+    const Scalar count_code = scalar_of(count_type), index_code = scalar_of(index_type);
+
     const size_t start_index = vertices.size() / 3;
     std::vector<V3> normals;
     std::vector<std::pair<float, float>> uvs;
@@ -132,15 +169,18 @@ bool load_ply(const std::string &path, std::vector<float> &vertices, HostScene &
 
     for (size_t vi = 0; vi < vertex_count; ++vi) {
         float vx = 0, vy = 0, vz = 0, nx = 0, ny = 0, nz = 0, vu = 0, vv = 0;
-        auto assign = [&](const std::string &name, float val) {
-            if (name == "x") vx = val;
-            else if (name == "y") vy = val;
-            else if (name == "z") vz = val;
-            else if (name == "nx") nx = val;
-            else if (name == "ny") ny = val;
-            else if (name == "nz") nz = val;
-            else if (name == "u" || name == "s") vu = val;
-            else if (name == "v" || name == "t") vv = val;
+        auto assign = [&](Slot slot, float val) {
+            switch (slot) {
+                case P_X: vx = val; break;
+                case P_Y: vy = val; break;
+                case P_Z: vz = val; break;
+                case P_NX: nx = val; break;
+                case P_NY: ny = val; break;
+                case P_NZ: nz = val; break;
+                case P_U: vu = val; break;
+                case P_V: vv = val; break;
+                default: break;
+            }
         };
         if (is_ascii) {
             if (!getline(line)) {
@@ -148,24 +188,23 @@ bool load_ply(const std::string &path, std::vector<float> &vertices, HostScene &
                 return false;
             }
             std::istringstream viss(line);
-            for (auto &prop : vprops) {
+            for (const auto &code : vcodes) {
                 std::string tok;
                 if (!(viss >> tok)) break;
-                if (prop.first == "list") continue;
-                assign(prop.second, strtof(tok.c_str(), nullptr));
+                if (code.first == S_LIST) continue;
+                assign(code.second, strtof(tok.c_str(), nullptr));
             }
         } else {
-            for (auto &prop : vprops) {
-                std::string type = lower(prop.first);
-                if (type == "list") {   // the reference skips a uchar count followed by uchar items
+            for (const auto &code : vcodes) {
+                if (code.first == S_LIST) {   // the reference skips a uchar count followed by uchar items
                     uint8_t n = 0;
                     if (!cur.take(&n, 1)) break;
                     cur.p = std::min(cur.p + n, cur.end);
                     continue;
                 }
                 double v;
-                if (read_scalar(cur, type, v)) {
-                    assign(prop.second, (float)v);
+                if (read_scalar(cur, code.first, v)) {
+                    assign(code.second, (float)v);
                 } else {
                     cur.p = std::min(cur.p + 4, cur.end);   // unknown type: the reference seeks 4 bytes
                 }
@@ -194,12 +233,12 @@ bool load_ply(const std::string &path, std::vector<float> &vertices, HostScene &
                 if (fiss >> idx) face.push_back(idx);
         } else {
             double c;
-            if (!read_scalar(cur, count_type, c)) break;
+            if (!read_scalar(cur, count_code, c)) break;
             n = (uint32_t)c;
             bool good = true;
             for (uint32_t j = 0; j < n; ++j) {
                 double v;
-                if (!read_scalar(cur, index_type, v)) {
+                if (!read_scalar(cur, index_code, v)) {
                     good = false;
                     break;
                 }
