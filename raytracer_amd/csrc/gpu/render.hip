@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1042,6 +1044,44 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, Wavefront &W) {
     return 0;
 }
 
+// One idle wavefront state per device is kept when a scene is destroyed and handed to the next scene created on
+// that device: a sequence of frames (one scene per file) would otherwise allocate and free gigabytes per frame, and
+// the driver answers that with occasional stalls of seconds.
+struct IdleWavefront {
+    Wavefront wf{};
+    std::vector<void *> allocations;
+};
+std::mutex g_idle_mutex;
+std::map<int, IdleWavefront> g_idle_wavefronts;
+
+static void adopt_idle_wavefront(rt_scene *s) {
+    std::lock_guard<std::mutex> lk(g_idle_mutex);
+    auto it = g_idle_wavefronts.find(s->device);
+    if (it == g_idle_wavefronts.end()) return;
+    s->wf = it->second.wf;
+    s->wf_allocations = std::move(it->second.allocations);
+    g_idle_wavefronts.erase(it);
+}
+
+// true when the scene's wavefront state was parked (the scene no longer owns it)
+static bool park_wavefront(rt_scene *s) {
+    if (!s->wf.capacity) return false;
+    std::lock_guard<std::mutex> lk(g_idle_mutex);
+    auto it = g_idle_wavefronts.find(s->device);
+    if (it != g_idle_wavefronts.end()) {
+        if (it->second.wf.capacity >= s->wf.capacity) return false;   // the parked one is at least as large: keep it
+        for (void *p : it->second.allocations) (void)hipFree(p);
+        g_idle_wavefronts.erase(it);
+    }
+    IdleWavefront idle;
+    idle.wf = s->wf;
+    idle.allocations = std::move(s->wf_allocations);
+    g_idle_wavefronts[s->device] = std::move(idle);
+    s->wf = Wavefront{};
+    s->wf_allocations.clear();
+    return true;
+}
+
 // Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries; grows, never shrinks.  When
 // the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
 static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
@@ -1050,12 +1090,16 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
     wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
     unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity());
     if (s->wf.capacity >= cap) return 0;
+    if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
+    if (!s->wf.capacity) {
+        adopt_idle_wavefront(s);
+        if (s->wf.capacity >= cap) return 0;
+    }
     HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipStreamSynchronize(s->stream2));
     for (void *p : s->wf_allocations) (void)hipFree(p);
     s->wf_allocations.clear();
     s->wf = Wavefront{};
-    if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
     for (;;) {
         Wavefront W{};
         if (allocate_wavefront(s, cap, W) == 0) {
@@ -1355,6 +1399,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
 
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
+    (void)hipSetDevice(s->device);
+    park_wavefront(s);
     for (void *p : s->allocations) (void)hipFree(p);
     for (void *p : s->wf_allocations) (void)hipFree(p);
     if (s->host_flags) (void)hipHostFree(s->host_flags);

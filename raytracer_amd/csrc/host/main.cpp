@@ -4,7 +4,8 @@
 // and process_file() (reference src/main.cpp:347-737).  The std::thread row/tile/pixel scheduler of
 // the reference (src/main.cpp:437-555) is replaced by one rt_render() call per camera; the threading
 // arguments are still parsed and validated so existing invocations keep working, but they no longer
-// select anything — the GPU schedules the pixels.  RT_GPU=<index> picks the device (default 0).
+// select anything — the GPU schedules the pixels.  RT_GPU=<index> picks the device; without it the files of a
+// directory are spread over all visible GPUs.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -14,11 +15,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <regex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "rt_host.h"
 #include "image_io.h"
@@ -83,94 +88,282 @@ static void create_videos_from_png_sequences(const std::string &folder) {
     }
 }
 
-static int process_file(const char *filename, int thread_count, int threading_type) {
-    static const char *names[] = {"row_dynamic", "row_static", "square_dynamic", "pixel_dynamic"};
-    log_printf("SIMD On / Thread count: %d / Threading type: %s\n", thread_count, names[threading_type]);
-    auto start = std::chrono::high_resolution_clock::now();
-    log_printf("JSON parsing started\n");
+// ---- a directory of scene files as a pipeline --------------------------------------------------------------------
+// The reference handles files one after the other on the main thread: parse, build, render, encode, write
+// (src/main.cpp:705-733).  With the render down to milliseconds the host stages dominate a sequence of frames, so
+// they run beside it: loader threads parse and build the next scenes, one render thread per GPU takes scenes in
+// file order (frame -> GPU, no communication between GPUs), writer threads encode and write the images.  Every
+// file's log lines are collected and printed in file order, so the log reads as the reference's does.
+struct FileJob {
+    std::string path, log;
     rth::HostScene scene;
-    std::string err;
-    if (!rth::load_scene(filename, scene, err)) {
-        log_printf("%s\n", err.c_str());
-        exit(-1);   // the reference exits on unreadable meshes / missing base meshes (src/parser.cpp:855, src/ply_loader.cpp:74)
-    }
-    for (auto &w : scene.warnings) log_printf("%s\n", w.c_str());
-    // the reference makes this check per camera, before it spawns its threads (src/main.cpp:542-545)
-    if (!scene.cameras.empty() && (thread_count > 4096 || thread_count < 1)) exit(-2);
-    rt_scene_desc desc = scene.desc();
-    rt_scene *gpu = nullptr;
-    if (rt_scene_create(&desc, &gpu) != 0) {
-        log_printf("rt_scene_create failed: %s\n", rt_last_error());
-        exit(-1);
-    }
-    auto end = std::chrono::high_resolution_clock::now();
-    log_printf("JSON parsing and grid preparation is done: %d ms\n", (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
+    std::string error;
+    bool loaded = false, load_ok = false, done = false;
+    std::chrono::high_resolution_clock::time_point start;
+};
 
-    for (auto &cam : scene.cameras) {
-        log_printf("%s started\n", cam.image_name.c_str());
-        start = std::chrono::high_resolution_clock::now();
-        const int W = cam.desc.resx, H = cam.desc.resy;
-        const std::string &name = cam.image_name;
-        const bool exr = cam.desc.is_hdr || (name.size() >= 4 && name.compare(name.size() - 4, 4, ".exr") == 0);
-        // Only an EXR needs the float frame on the host; for PNG outputs the frame stays in HBM and is tone-mapped
-        // or quantised there (rt_tonemap / rt_quantize_ldr), so 8-bit pixels are all that crosses PCIe.
-        std::vector<float> hdr;
-        float *frame = nullptr, *device_frame = nullptr;
-        if (exr) {
-            hdr.assign((size_t)W * H * 3, 0.0f);
-            frame = hdr.data();
-        } else {
-            if (hipMalloc((void **)&device_frame, (size_t)W * H * 3 * sizeof(float)) != hipSuccess) {
-                log_printf("cannot allocate the device framebuffer\n");
-                exit(-1);
-            }
-            frame = device_frame;
-        }
-        rt_stats stats;
-        if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
-            log_printf("rt_render failed: %s\n", rt_last_error());
-            exit(-1);
-        }
-        end = std::chrono::high_resolution_clock::now();
-        log_printf("%s rendering done: %d ms\n", cam.image_name.c_str(), (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
-        const unsigned long long rays = stats.primary_rays + stats.shadow_rays + stats.secondary_rays;
-        log_printf("%s rays: %llu primary, %llu shadow, %llu secondary; device %.3f ms; %.1f Mrays/s\n", cam.image_name.c_str(),
-                   (unsigned long long)stats.primary_rays, (unsigned long long)stats.shadow_rays, (unsigned long long)stats.secondary_rays,
-                   stats.kernel_ms, stats.kernel_ms > 0 ? rays / stats.kernel_ms / 1e3 : 0.0);
+struct WriteTask {
+    enum Kind { PNG_RGB8, EXR_RGB32F } kind;
+    std::string path;
+    int width, height;
+    std::vector<uint8_t> rgb8;
+    std::vector<float> rgb32f;
+};
 
-        const size_t n_values = (size_t)W * H * 3;
-        if (exr) {
-            log_printf("%s write EXR started\n", name.c_str());
-            if (!rth::write_exr_rgb32f("outputs/" + name, W, H, hdr.data())) fprintf(stderr, "Save EXR Error: cannot write outputs/%s\n", name.c_str());
-        } else if (cam.tonemaps.empty()) {
-            std::vector<uint8_t> ldr(n_values);
-            if (rt_quantize_ldr(frame, (int64_t)n_values, ldr.data()) != 0) {
-                log_printf("rt_quantize_ldr failed: %s\n", rt_last_error());
-                exit(-1);
-            }
-            rth::write_png_rgb8("outputs/" + name, W, H, ldr.data(), true);
+static void job_printf(FileJob &job, const char *fmt, ...) {
+    char buf[1024];
+    va_list args;
+    va_start(args, fmt);
+    vsnprintf(buf, sizeof buf, fmt, args);
+    va_end(args);
+    job.log += buf;
+}
+
+class Pipeline {
+public:
+    Pipeline(std::vector<std::string> files, int thread_count, int threading_type, std::vector<int> gpus)
+        : thread_count_(thread_count), threading_type_(threading_type), gpus_(std::move(gpus)) {
+        jobs_.resize(files.size());
+        for (size_t i = 0; i < files.size(); ++i) jobs_[i].path = files[i];
+    }
+
+    void run() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), std::max(1u, std::min(4u, hw / 2)));
+        const unsigned n_write = std::max(1u, std::min(4u, hw / 2));
+        std::vector<std::thread> loaders, renderers, writers;
+        for (unsigned i = 0; i < n_load; ++i) loaders.emplace_back([this] { load_loop(); });
+        for (unsigned i = 0; i < n_write; ++i) writers.emplace_back([this] { write_loop(); });
+        for (int g : gpus_) renderers.emplace_back([this, g] { render_loop(g); });
+        for (auto &t : loaders) t.join();
+        for (auto &t : renderers) t.join();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            writers_may_stop_ = true;
         }
-        if (!cam.tonemaps.empty()) {
-            std::vector<uint8_t> tm_out(n_values);
-            for (auto &tm : cam.tonemaps) {
-                const rt_tonemap_desc td{tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma};
-                if (rt_tonemap(frame, W, H, &td, tm_out.data()) != 0) {
-                    log_printf("rt_tonemap failed: %s\n", rt_last_error());
-                    exit(-1);
+        cv_.notify_all();
+        for (auto &t : writers) t.join();
+    }
+
+private:
+    // ---- stage 1: parse + BVH build, at most `ahead` files beyond the one being rendered ----------------------
+    void load_loop() {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                i = next_load_++;
+                if (i >= jobs_.size()) return;
+                const size_t ahead = 2 * gpus_.size() + 2;
+                cv_.wait(lk, [&] { return i < flushed_ + ahead; });
+            }
+            FileJob &job = jobs_[i];
+            static const char *names[] = {"row_dynamic", "row_static", "square_dynamic", "pixel_dynamic"};
+            job_printf(job, "SIMD On / Thread count: %d / Threading type: %s\n", thread_count_, names[threading_type_]);
+            job.start = std::chrono::high_resolution_clock::now();
+            job_printf(job, "JSON parsing started\n");
+            const bool ok = rth::load_scene(job.path, job.scene, job.error);
+            if (getenv("RT_CLI_TIMING"))
+                job_printf(job, "[timing] load %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - job.start).count());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                job.load_ok = ok;
+                job.loaded = true;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    // the reference exits the process where it fails; earlier files' log lines come out first
+    [[noreturn]] void fail(size_t index, int code) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return flushed_ == index; });
+        log_printf("%s", jobs_[index].log.c_str());
+        fflush(stdout);
+        _exit(code & 0xff);
+    }
+
+    // ---- stage 2: one thread per GPU, scenes in file order ----------------------------------------------------
+    void render_loop(int gpu_index) {
+        for (;;) {
+            size_t i;
+            const auto t_wait = std::chrono::high_resolution_clock::now();
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                i = next_render_++;
+                if (i >= jobs_.size()) return;
+                cv_.wait(lk, [&] { return jobs_[i].loaded; });
+            }
+            FileJob &job = jobs_[i];
+            if (getenv("RT_CLI_TIMING"))
+                job_printf(job, "[timing] render thread waited %.1f ms for this file\n",
+                           std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_wait).count());
+            if (!job.load_ok) {
+                job_printf(job, "%s\n", job.error.c_str());
+                fail(i, -1);   // unreadable meshes / missing base meshes (src/parser.cpp:855, src/ply_loader.cpp:74)
+            }
+            for (auto &w : job.scene.warnings) job_printf(job, "%s\n", w.c_str());
+            // the reference makes this check per camera, before it spawns its threads (src/main.cpp:542-545)
+            if (!job.scene.cameras.empty() && (thread_count_ > 4096 || thread_count_ < 1)) fail(i, -2);
+            render_scene(i, job, gpu_index);
+            const auto t_tail = std::chrono::high_resolution_clock::now();
+            job.scene = rth::HostScene();   // release the host arrays
+            const double free_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_tail).count();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                job.done = true;
+                while (flushed_ < jobs_.size() && jobs_[flushed_].done) {
+                    log_printf("%s", jobs_[flushed_].log.c_str());
+                    jobs_[flushed_].log.clear();
+                    ++flushed_;
                 }
+            }
+            cv_.notify_all();
+            if (getenv("RT_CLI_TIMING"))
+                fprintf(stderr, "[timing] file %zu: release %.1f ms, release + log flush %.1f ms (at %.0f ms)\n", i, free_ms,
+                        std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_tail).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now().time_since_epoch()).count() - 1.7e12);
+        }
+    }
+
+    void render_scene(size_t index, FileJob &job, int gpu_index) {
+        static const bool timing = getenv("RT_CLI_TIMING") != nullptr;   // diagnostic: stage times per file
+        auto t_begin = std::chrono::high_resolution_clock::now();
+        auto since = [&](std::chrono::high_resolution_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t).count();
+        };
+        if (hipSetDevice(gpu_index) != hipSuccess) {   // the device is a per-thread setting
+            job_printf(job, "Error: cannot select GPU %d\n", gpu_index);
+            fail(index, 1);
+        }
+        rt_scene_desc desc = job.scene.desc();
+        rt_scene *gpu = nullptr;
+        if (rt_scene_create(&desc, &gpu) != 0) {
+            job_printf(job, "rt_scene_create failed: %s\n", rt_last_error());
+            fail(index, -1);
+        }
+        auto end = std::chrono::high_resolution_clock::now();
+        job_printf(job, "JSON parsing and grid preparation is done: %d ms\n",
+                   (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - job.start).count());
+        if (timing) job_printf(job, "[timing] waited for the render thread since load start, scene upload %.1f ms\n", since(t_begin));
+        for (auto &cam : job.scene.cameras) {
+            job_printf(job, "%s started\n", cam.image_name.c_str());
+            auto start = std::chrono::high_resolution_clock::now();
+            const int W = cam.desc.resx, H = cam.desc.resy;
+            const std::string &name = cam.image_name;
+            const bool exr = cam.desc.is_hdr || (name.size() >= 4 && name.compare(name.size() - 4, 4, ".exr") == 0);
+            const size_t n_values = (size_t)W * H * 3;
+            // Only an EXR needs the float frame on the host; for PNG outputs the frame stays in HBM and is tone-mapped
+            // or quantised there (rt_tonemap / rt_quantize_ldr), so 8-bit pixels are all that crosses PCIe.
+            WriteTask exr_task{WriteTask::EXR_RGB32F, "outputs/" + name, W, H, {}, {}};
+            float *frame = nullptr, *device_frame = nullptr;
+            if (exr) {
+                exr_task.rgb32f.assign(n_values, 0.0f);
+                frame = exr_task.rgb32f.data();
+            } else {
+                if (hipMalloc((void **)&device_frame, n_values * sizeof(float)) != hipSuccess) {
+                    job_printf(job, "cannot allocate the device framebuffer\n");
+                    fail(index, -1);
+                }
+                frame = device_frame;
+            }
+            rt_stats stats;
+            if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
+                job_printf(job, "rt_render failed: %s\n", rt_last_error());
+                fail(index, -1);
+            }
+            end = std::chrono::high_resolution_clock::now();
+            job_printf(job, "%s rendering done: %d ms\n", name.c_str(), (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
+            const unsigned long long rays = stats.primary_rays + stats.shadow_rays + stats.secondary_rays;
+            job_printf(job, "%s rays: %llu primary, %llu shadow, %llu secondary; device %.3f ms; %.1f Mrays/s\n", name.c_str(),
+                       (unsigned long long)stats.primary_rays, (unsigned long long)stats.shadow_rays, (unsigned long long)stats.secondary_rays,
+                       stats.kernel_ms, stats.kernel_ms > 0 ? rays / stats.kernel_ms / 1e3 : 0.0);
+
+            std::vector<WriteTask> tasks;
+            if (!exr && cam.tonemaps.empty()) {
+                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + name, W, H, std::vector<uint8_t>(n_values), {}};
+                if (rt_quantize_ldr(frame, (int64_t)n_values, t.rgb8.data()) != 0) {
+                    job_printf(job, "rt_quantize_ldr failed: %s\n", rt_last_error());
+                    fail(index, -1);
+                }
+                tasks.push_back(std::move(t));
+            }
+            for (auto &tm : cam.tonemaps) {
                 std::string base = name;
                 size_t dot = base.find_last_of('.');
                 if (dot != std::string::npos) base = base.substr(0, dot);
-                std::string tm_name = base + tm.extension;
-                log_printf("Saving tone mapped image: %s\n", tm_name.c_str());
-                rth::write_png_rgb8("outputs/" + tm_name, W, H, tm_out.data(), true);
+                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + base + tm.extension, W, H, std::vector<uint8_t>(n_values), {}};
+                const rt_tonemap_desc td{tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma};
+                if (rt_tonemap(frame, W, H, &td, t.rgb8.data()) != 0) {
+                    job_printf(job, "rt_tonemap failed: %s\n", rt_last_error());
+                    fail(index, -1);
+                }
+                tasks.push_back(std::move(t));
+            }
+            if (exr) {
+                job_printf(job, "%s write EXR started\n", name.c_str());
+                submit(std::move(exr_task));
+            }
+            for (auto &t : tasks) {
+                if (!cam.tonemaps.empty()) job_printf(job, "Saving tone mapped image: %s\n", t.path.substr(strlen("outputs/")).c_str());
+                submit(std::move(t));
+            }
+            if (device_frame) (void)hipFree(device_frame);
+            if (timing) job_printf(job, "[timing] camera total %.1f ms (render + tone map + hand-off)\n", since(start));
+        }
+        auto t_destroy = std::chrono::high_resolution_clock::now();
+        rt_scene_destroy(gpu);
+        if (timing) job_printf(job, "[timing] destroy %.1f ms, scene total on the render thread %.1f ms\n", since(t_destroy), since(t_begin));
+    }
+
+    // ---- stage 3: encode and write ---------------------------------------------------------------------------
+    void submit(WriteTask &&t) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return write_queue_.size() < 8; });   // bounds the frames held in host memory
+        write_queue_.push_back(std::move(t));
+        lk.unlock();
+        cv_.notify_all();
+    }
+
+    void write_loop() {
+        for (;;) {
+            WriteTask t;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !write_queue_.empty() || writers_may_stop_; });
+                if (write_queue_.empty()) return;
+                t = std::move(write_queue_.front());
+                write_queue_.erase(write_queue_.begin());
+            }
+            cv_.notify_all();
+            const auto t_write = std::chrono::high_resolution_clock::now();
+            struct Report {
+                std::chrono::high_resolution_clock::time_point t0;
+                const std::string &path;
+                ~Report() {
+                    if (getenv("RT_CLI_TIMING"))
+                        fprintf(stderr, "[timing] wrote %s in %.1f ms (at %.0f ms)\n", path.c_str(),
+                                std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(),
+                                std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now().time_since_epoch()).count() - 1.7e12);
+                }
+            } report{t_write, t.path};
+            if (t.kind == WriteTask::EXR_RGB32F) {
+                if (!rth::write_exr_rgb32f(t.path, t.width, t.height, t.rgb32f.data())) fprintf(stderr, "Save EXR Error: cannot write %s\n", t.path.c_str());
+            } else {
+                rth::write_png_rgb8(t.path, t.width, t.height, t.rgb8.data(), true);
             }
         }
-        if (device_frame) (void)hipFree(device_frame);
     }
-    rt_scene_destroy(gpu);
-    return 0;
-}
+
+    int thread_count_, threading_type_;
+    std::vector<int> gpus_;
+    std::vector<FileJob> jobs_;
+    std::vector<WriteTask> write_queue_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    size_t next_load_ = 0, next_render_ = 0, flushed_ = 0;
+    bool writers_may_stop_ = false;
+};
 
 int main(int argc, char **argv) {
     log_printf("\n>>> NEW RUN <<<\n");
@@ -195,11 +388,14 @@ int main(int argc, char **argv) {
         log_printf("Invalid thread count\n");
         return -1;
     }
+    // RT_GPU=<index> renders on that device; otherwise the files of a directory are spread over every visible GPU
+    std::vector<int> gpus;
     if (const char *dev = getenv("RT_GPU")) {
-        if (hipSetDevice(atoi(dev)) != hipSuccess) {
-            log_printf("Error: cannot select GPU %s\n", dev);
-            return 1;
-        }
+        gpus.push_back(atoi(dev));
+    } else {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count < 1) count = 1;   // the first HIP call of the render thread reports the error
+        for (int g = 0; g < count; ++g) gpus.push_back(g);
     }
     std::vector<std::string> files;
     std::string input = argv[1];
@@ -212,7 +408,12 @@ int main(int argc, char **argv) {
         log_printf("Error: %s is neither a .json file nor a directory.\n", input.c_str());
         return 1;
     }
-    for (auto &f : files) process_file(f.c_str(), thread_count, tt);
+    if (gpus.size() > files.size()) gpus.resize(std::max<size_t>(1, files.size()));
+    const auto t_run = std::chrono::high_resolution_clock::now();
+    Pipeline(files, thread_count, tt, gpus).run();
+    if (getenv("RT_CLI_TIMING"))
+        log_printf("[timing] %zu file(s) in %.1f ms\n", files.size(),
+                   std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_run).count());
     create_videos_from_png_sequences("outputs");
     return 0;
 }

@@ -1,0 +1,29 @@
+"""Config 5 rehearsal: 120 JSON frames (70K-triangle mesh, moving camera, 1920x1080) through ./raytracer <dir>,
+timed end to end, next to the reference executable on the same frames when it is present."""
+import json, os, shutil, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import scenegen
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+work = tempfile.mkdtemp(prefix="rt_anim_")
+frames = os.path.join(work, "frames")
+base = scenegen.write_mesh_scene(frames, name="anim_0000", n=188, width=1920, height=1080)
+doc = json.load(open(base))
+import math
+for k in range(n):
+    cam = doc["Scene"]["Cameras"]["Camera"]
+    a = 2 * math.pi * k / n
+    cam["Position"] = f"{3.2 * math.sin(a):.5f} 0.5 {3.2 * math.cos(a):.5f}"
+    cam["ImageName"] = f"anim_{k:04d}.png"
+    json.dump(doc, open(os.path.join(frames, f"anim_{k:04d}.json"), "w"))
+for label, exe in (("this repository", os.path.join(ROOT, "raytracer")), ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"))):
+    if not os.path.exists(exe):
+        continue
+    cwd = os.path.join(work, label.split()[0])
+    os.makedirs(cwd)
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, frames], cwd=cwd, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    done = sum(1 for f in os.listdir(os.path.join(cwd, "outputs")) if f.endswith(".png"))
+    print(f"{label}: {n} frames in {dt:.2f} s = {n / dt:.1f} frames/s ({done} PNGs written, exit {r.returncode})")
+shutil.rmtree(work, ignore_errors=True)
