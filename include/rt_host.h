@@ -38,6 +38,9 @@ int rth_write_png(const char *path, int32_t width, int32_t height, const uint8_t
 int rth_write_exr(const char *path, int32_t width, int32_t height, const float *rgb);
 /* Reads an EXR into caller memory of width*height*4 floats; pass rgba=NULL to query the size. */
 int rth_read_exr(const char *path, int32_t *width, int32_t *height, float *rgba);
+/* Decodes an 8-bit texture file held in memory (PNG, else JPEG) to RGB, as the reference's
+ * stbi_load(path, &w, &h, &n, 3) does (reference src/texture.cpp:46); pass rgb8=NULL to query the size. */
+int rth_decode_image_rgb8(const uint8_t *file, int64_t n_bytes, int32_t *width, int32_t *height, uint8_t *rgb8);
 
 const char *rth_last_error(void);
 

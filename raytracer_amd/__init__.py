@@ -49,6 +49,7 @@ def host_lib():
         h.rth_write_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         h.rth_write_exr.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
         h.rth_read_exr.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
+        h.rth_decode_image_rgb8.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
         h.rth_last_error.restype = C.c_char_p
         _host = h
     return _host

@@ -88,6 +88,19 @@ int rth_read_exr(const char *path, int32_t *w, int32_t *h, float *rgba) {
     if (rgba) memcpy(rgba, data.data(), data.size() * sizeof(float));
     return 0;
 }
+int rth_decode_image_rgb8(const uint8_t *file, int64_t n_bytes, int32_t *w, int32_t *h, uint8_t *rgb8) {
+    std::vector<uint8_t> bytes(file, file + n_bytes), rgb;
+    std::string err;
+    int ww = 0, hh = 0;
+    if (!rth::decode_image_rgb8(bytes, ww, hh, rgb, err)) {
+        g_error = err;
+        return 1;
+    }
+    *w = ww;
+    *h = hh;
+    if (rgb8) memcpy(rgb8, rgb.data(), rgb.size());
+    return 0;
+}
 const char *rth_last_error(void) { return g_error.c_str(); }
 
 }  // extern "C"

@@ -332,6 +332,10 @@ void png_chunk(std::vector<uint8_t> &out, const char *type, const std::vector<ui
 
 }  // namespace
 
+bool decode_image_rgb8(const std::vector<uint8_t> &file, int &w, int &h, std::vector<uint8_t> &rgb, std::string &err) {
+    return decode_png(file, w, h, rgb, err) || decode_jpeg(file, w, h, rgb, err);
+}
+
 bool load_image_file(const std::string &path, HostScene &scene, rt_image &out, std::string &err) {
     std::vector<uint8_t> file;
     if (!read_all(path, file)) {
@@ -352,9 +356,7 @@ bool load_image_file(const std::string &path, HostScene &scene, rt_image &out, s
         return true;
     }
     std::vector<uint8_t> rgb;
-    if (!decode_png(file, w, h, rgb, err)) {
-        if (!decode_jpeg(file, w, h, rgb, err)) return false;
-    }
+    if (!decode_image_rgb8(file, w, h, rgb, err)) return false;
     out.width = w;
     out.height = h;
     out.is_hdr = 0;

@@ -183,3 +183,37 @@ def test_cli_argument_validation(args, code, text, tmp_path):
     r = subprocess.run([CLI] + args, cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode == code, (r.stdout, r.stderr)
     assert text in r.stdout + r.stderr
+
+
+def _decode_image(data):
+    h = R.host_lib()
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    w, hh = C.c_int32(), C.c_int32()
+    if h.rth_decode_image_rgb8(buf.ctypes.data, buf.size, C.byref(w), C.byref(hh), None) != 0:
+        return None
+    rgb = np.empty((hh.value, w.value, 3), dtype=np.uint8)
+    assert h.rth_decode_image_rgb8(buf.ctypes.data, buf.size, C.byref(w), C.byref(hh), rgb.ctypes.data) == 0
+    return rgb
+
+
+_JPEG = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in _JPEG["names"]])
+def test_jpeg_texels_match_reference_decoder(name):
+    """JPEG textures decode to the very bytes the reference's decoder yields (fixtures: tests/golden/make_jpeg_golden.py):
+    baseline and progressive, every chroma layout, restart intervals, grey / CMYK / YCCK / RGB-tagged files."""
+    want = _JPEG["rgb_" + name]
+    got = _decode_image(_JPEG["file_" + name])
+    assert got is not None, R.host_lib().rth_last_error()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} bytes differ, max {np.abs(got.astype(int) - want).max()}"
+
+
+def test_jpeg_rejects_garbage():
+    assert _decode_image(b"\xff\xd8\xff\xd9") is None          # no frame
+    assert _decode_image(b"not an image at all") is None
+    ok = bytes(_JPEG["file_pil_444"])
+    assert _decode_image(ok[:40]) is None                       # cut before the frame header
+    sof = ok.index(b"\xff\xc0")
+    assert _decode_image(ok[:sof + 4] + b"\x0c" + ok[sof + 5:]) is None   # 12-bit samples
