@@ -51,7 +51,7 @@ int paeth(int a, int b, int c) {
     return pb <= pc ? b : c;
 }
 
-// PNG -> 8-bit RGB.  Colour types 0,2,3,4,6; bit depths 1..16; no interlace.
+// PNG -> 8-bit RGB.  Colour types 0,2,3,4,6; bit depths 1..16; plain or Adam7-interlaced.
 bool decode_png(const std::vector<uint8_t> &file, int &w, int &h, std::vector<uint8_t> &rgb, std::string &err) {
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) {
@@ -82,72 +82,101 @@ bool decode_png(const std::vector<uint8_t> &file, int &w, int &h, std::vector<ui
         }
         p += 12 + len;
     }
-    if (w <= 0 || h <= 0 || interlace) {
-        err = "unsupported PNG (interlaced or empty)";
+    if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > (1ull << 28) || interlace > 1) {
+        err = "unsupported PNG (bad size or interlace method)";
         return false;
     }
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!channels) {
-        err = "bad PNG colour type";
+    if (!channels || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)) {
+        err = "bad PNG colour type or bit depth";
         return false;
     }
-    int bpp_bits = channels * depth;
-    size_t stride = ((size_t)w * bpp_bits + 7) / 8;
-    int bpp = std::max(1, bpp_bits / 8);
+    const int bpp_bits = channels * depth;
+    const int bpp = std::max(1, bpp_bits / 8);
+    // the image is one pass, or the seven Adam7 passes (x origin, y origin, x spacing, y spacing), each filtered on its own
+    struct Pass {
+        int x0, y0, dx, dy;
+    };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass *passes = interlace ? adam7 : &whole;
+    const int n_passes = interlace ? 7 : 1;
+    auto pass_size = [&](const Pass &ps, int &pw, int &ph, size_t &stride) {
+        pw = (w - ps.x0 + ps.dx - 1) / ps.dx;
+        ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        stride = ((size_t)pw * bpp_bits + 7) / 8;
+    };
+    size_t total = 0;
+    for (int i = 0; i < n_passes; ++i) {
+        int pw, ph;
+        size_t stride;
+        pass_size(passes[i], pw, ph, stride);
+        if (pw > 0 && ph > 0) total += (stride + 1) * (size_t)ph;
+    }
     std::vector<uint8_t> raw;
-    if (!zlib_inflate(idat.data(), idat.size(), raw, (stride + 1) * (size_t)h) || raw.size() != (stride + 1) * (size_t)h) {
+    if (!zlib_inflate(idat.data(), idat.size(), raw, total) || raw.size() != total) {
         err = "PNG inflate failed";
         return false;
     }
-    std::vector<uint8_t> img(stride * (size_t)h);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t *src = &raw[(stride + 1) * y];
-        uint8_t *dst = &img[stride * y];
-        const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
-        int filter = src[0];
-        for (size_t x = 0; x < stride; ++x) {
-            int a = x >= (size_t)bpp ? dst[x - bpp] : 0;
-            int b = up ? up[x] : 0;
-            int c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
-            int v = src[x + 1];
-            switch (filter) {
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) / 2; break;
-                case 4: v += paeth(a, b, c); break;
-                default: break;
-            }
-            dst[x] = (uint8_t)v;
-        }
-    }
     rgb.resize((size_t)w * h * 3);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t *row = &img[stride * y];
-        for (int x = 0; x < w; ++x) {
-            int s[4] = {0, 0, 0, 255};
-            for (int c = 0; c < channels; ++c) {
-                if (depth == 8) {
-                    s[c] = row[x * channels + c];
-                } else if (depth == 16) {
-                    s[c] = row[(x * channels + c) * 2];
-                } else {
-                    int bit = (x * channels + c) * depth;
-                    int v = (row[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
-                    s[c] = ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+    size_t at = 0;
+    std::vector<uint8_t> img;
+    for (int i = 0; i < n_passes; ++i) {
+        const Pass &ps = passes[i];
+        int pw, ph;
+        size_t stride;
+        pass_size(ps, pw, ph, stride);
+        if (pw <= 0 || ph <= 0) continue;
+        img.assign(stride * (size_t)ph, 0);
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t *src = &raw[at + (stride + 1) * y];
+            uint8_t *dst = &img[stride * y];
+            const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
+            int filter = src[0];
+            for (size_t x = 0; x < stride; ++x) {
+                int a = x >= (size_t)bpp ? dst[x - bpp] : 0;
+                int b = up ? up[x] : 0;
+                int c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
+                int v = src[x + 1];
+                switch (filter) {
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) / 2; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: break;
                 }
+                dst[x] = (uint8_t)v;
             }
-            uint8_t *o = &rgb[((size_t)y * w + x) * 3];
-            if (ctype == 3) {
-                size_t k = (size_t)s[0] * 3;
-                o[0] = k + 2 < palette.size() ? palette[k] : 0;
-                o[1] = k + 2 < palette.size() ? palette[k + 1] : 0;
-                o[2] = k + 2 < palette.size() ? palette[k + 2] : 0;
-            } else if (channels <= 2) {
-                o[0] = o[1] = o[2] = (uint8_t)s[0];
-            } else {
-                o[0] = (uint8_t)s[0];
-                o[1] = (uint8_t)s[1];
-                o[2] = (uint8_t)s[2];
+        }
+        at += (stride + 1) * (size_t)ph;
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t *row = &img[stride * y];
+            for (int x = 0; x < pw; ++x) {
+                int s[4] = {0, 0, 0, 255};
+                for (int c = 0; c < channels; ++c) {
+                    if (depth == 8) {
+                        s[c] = row[x * channels + c];
+                    } else if (depth == 16) {
+                        s[c] = row[(x * channels + c) * 2];
+                    } else {
+                        int bit = (x * channels + c) * depth;
+                        int v = (row[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+                        s[c] = ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+                    }
+                }
+                uint8_t *o = &rgb[((size_t)(y * ps.dy + ps.y0) * w + (size_t)(x * ps.dx + ps.x0)) * 3];
+                if (ctype == 3) {
+                    size_t k = (size_t)s[0] * 3;
+                    o[0] = k + 2 < palette.size() ? palette[k] : 0;
+                    o[1] = k + 2 < palette.size() ? palette[k + 1] : 0;
+                    o[2] = k + 2 < palette.size() ? palette[k + 2] : 0;
+                } else if (channels <= 2) {
+                    o[0] = o[1] = o[2] = (uint8_t)s[0];
+                } else {
+                    o[0] = (uint8_t)s[0];
+                    o[1] = (uint8_t)s[1];
+                    o[2] = (uint8_t)s[2];
+                }
             }
         }
     }

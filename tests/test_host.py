@@ -217,3 +217,17 @@ def test_jpeg_rejects_garbage():
     assert _decode_image(ok[:40]) is None                       # cut before the frame header
     sof = ok.index(b"\xff\xc0")
     assert _decode_image(ok[:sof + 4] + b"\x0c" + ok[sof + 5:]) is None   # 12-bit samples
+
+
+_PNG = np.load(os.path.join(os.path.dirname(__file__), "golden", "png.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in _PNG["names"]])
+def test_png_texels_match_reference_decoder(name):
+    """PNG textures of every colour type, bit depth, row filter and interlace method decode to the bytes the reference's
+    decoder yields (fixtures: tests/golden/make_png_golden.py)."""
+    want = _PNG["rgb_" + name]
+    got = _decode_image(_PNG["file_" + name])
+    assert got is not None, R.host_lib().rth_last_error()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} bytes differ"
