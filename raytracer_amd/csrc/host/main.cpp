@@ -275,7 +275,7 @@ private:
             end = std::chrono::high_resolution_clock::now();
             job_printf(job, "%s rendering done: %d ms\n", name.c_str(), (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
             const unsigned long long rays = stats.primary_rays + stats.shadow_rays + stats.secondary_rays;
-            job_printf(job, "%s rays: %llu primary, %llu shadow, %llu secondary; device %.3f ms; %.1f Mrays/s\n", name.c_str(),
+            job_printf(job, "%s rays: %llu primary, %llu light samples, %llu secondary; device %.3f ms; %.1f Mrays/s\n", name.c_str(),
                        (unsigned long long)stats.primary_rays, (unsigned long long)stats.shadow_rays, (unsigned long long)stats.secondary_rays,
                        stats.kernel_ms, stats.kernel_ms > 0 ? rays / stats.kernel_ms / 1e3 : 0.0);
 
