@@ -60,6 +60,11 @@ thread_local std::string g_error;
 // added to a slot, and a slot's random numbers depend only on (seed, pixel, sample, path node).
 // =====================================================================================================
 
+// waves per SIMD of the trace kernel: 5 measured fastest (4: 475 ms, 5: 426 ms, 6: 438 ms, 7: 459 ms, 8: 467 ms of closest-hit
+// time per 4K / 64 spp frame of the 1M-triangle scene) -- more waves evict each other's part of the tree from the caches
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5
+#endif
 constexpr int MAX_GENERATIONS = 66;   // queue generations per batch (depth limit + 2)
 
 struct PathQueue {
@@ -241,7 +246,7 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
 }
 
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
     uint2 *lds = stack_lds + threadIdx.x;
     uint2 spill[SPILL_STACK];

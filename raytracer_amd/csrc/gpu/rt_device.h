@@ -80,8 +80,11 @@ struct Hit {
 //   cur < 0              leaf: 1<<31 | (entries left - 1) << 24 | next leaf entry
 //   REF_POP              take the next node from the stack
 //   REF_IDLE             no ray
-constexpr int LDS_STACK = 12;
-constexpr int SPILL_STACK = 52;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12
+#endif
+constexpr int LDS_STACK = RT_LDS_STACK;
+constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
 constexpr int REF_POP = 0x40000000;
 constexpr int REF_IDLE = 0x40000001;
 constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's placement index: the placement moves or transforms the ray
