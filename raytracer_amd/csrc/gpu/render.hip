@@ -724,10 +724,13 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
         const unsigned vl = vbase + lane;
         const bool valid = vl < nv;
         const unsigned v = shard_base + (valid ? vl : vbase);
-        const float4 pt = W.vtx[gen & 1].p_time[v], nk = W.vtx[gen & 1].n_key[v], vm = W.vtx[gen & 1].view_mat[v], kds = W.vtx[gen & 1].kd_slot[v], ksn = W.vtx[gen & 1].ks_n[v];
-        const V p = mk(pt.x, pt.y, pt.z), normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z);
-        const V kd = mk(kds.x, kds.y, kds.z), ks = mk(ksn.x, ksn.y, ksn.z);
-        const uint32_t key = __float_as_uint(nk.w);
+        const float4 pt = W.vtx[gen & 1].p_time[v];
+        const V p = mk(pt.x, pt.y, pt.z);
+        // the rest of the vertex is read when the first light that is evaluated here comes up (a deferred one needs none)
+        float4 nk = make_float4(0, 0, 0, 0), vm = nk, ksn = nk;
+        V normal = mk(0, 0, 0), view = normal, kd = normal, ks = normal;
+        uint32_t key = 0;
+        bool vertex_read = false;
         const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
         if (!room) *W.overflow = 1u;
         unsigned long long have = 0;
@@ -744,7 +747,6 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             const unsigned k = (unsigned)(k0 + kl);
             const int li = light_of[k];
             const rt_light &L = S.lights[li];
-            const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
             V rad, ldir, fd = mk(0, 0, 0), fs = mk(0, 0, 0);
             float dist;
             bool want;
@@ -754,6 +756,8 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 if (li != kept_light) {   // (uniform over the wave)
                     kept_light = li;
                     sphere_light_geometry(S.spheres[L.sphere], p, kept_ldir, kept_dist, kept_d2);
+                    // every vertex of the block gets a ray, so their rays are consecutive: ray of lane i = ray of lane 0 + i,
+                    // and only lane 0's index is recorded (in the slot of its record for this sample)
                     const unsigned ray_local = wave_append(valid, ray_count);
                     if (valid && ray_local >= W.shadow_shard_entries) *W.overflow = 1u;
                     if (valid && room) {
@@ -762,14 +766,22 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                         const V so = add(p, scl(kept_ldir, seps));
                         W.shadow[gen & 1].o_dist[ray_index] = make_float4(so.x, so.y, so.z, kept_dist);
                         W.shadow[gen & 1].d_time[ray_index] = make_float4(kept_ldir.x, kept_ldir.y, kept_ldir.z, pt.w);
-                        const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
-                        ((float *)&W.shadow[gen & 1].fd_ray[ri])[3] = __uint_as_float(ray_index);
-                        have |= 1ull << kl;
+                        if (lane == 0)
+                            ((float *)&W.shadow[gen & 1].fd_ray[record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u)])[3] = __uint_as_float(ray_index);
                     }
                 }
                 prev_light = -1;
+                kl = min(kn, light_of[k_total + li] + L.samples - k0) - 1;   // on to the next light
                 continue;
             }
+            if (!vertex_read) {   // (uniform over the wave)
+                vertex_read = true;
+                const float4 kds = W.vtx[gen & 1].kd_slot[v];
+                nk = W.vtx[gen & 1].n_key[v], vm = W.vtx[gen & 1].view_mat[v], ksn = W.vtx[gen & 1].ks_n[v];
+                normal = mk(nk.x, nk.y, nk.z), view = mk(vm.x, vm.y, vm.z), kd = mk(kds.x, kds.y, kds.z), ks = mk(ksn.x, ksn.y, ksn.z);
+                key = __float_as_uint(nk.w);
+            }
+            const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
             if (L.type == RT_LIGHT_SPHERE) {
                 const rt_sphere &sph = S.spheres[L.sphere];
                 if (li != kept_light) {
@@ -825,9 +837,9 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 prev_light = fixed_position ? li : -1;
             }
         }
-        if (valid) {   // which of the vertex's samples have a record
+        if (valid && (have != 0 || pass > 0)) {   // which of the vertex's samples have a record (shade_kernel wrote "none")
             ((float *)&W.vtx[gen & 1].amb_first[v])[3] = __uint_as_float((unsigned)have);
-            ((float *)&W.vtx[gen & 1].weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
+            if (kn > 32) ((float *)&W.vtx[gen & 1].weight[v])[3] = __uint_as_float((unsigned)(have >> 32));
         }
     }
     flush_counters(c, stats, false);
@@ -836,52 +848,54 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
 // Adds the direct lighting of one vertex (lane-local): every light sample of the pass in sample order.  A sample of a
 // deferred sphere light is evaluated here when the light's ray arrived; any other sample contributes its record.
 __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W, int gen, unsigned v, unsigned vl, unsigned shadow_base,
-                                           const int *__restrict__ light_of, int k0, int kn, int k_pad, int defer, unsigned long long have, V c,
-                                           Counters &cnt) {
+                                           const int *__restrict__ light_of, int k_total, int k0, int kn, int k_pad, int defer, bool active,
+                                           unsigned long long have, V c, Counters &cnt) {
     const VertexBuf &B = W.vtx[gen & 1];
     const ShadowQueue &Q = W.shadow[gen & 1];
     const unsigned vbase = vl & ~63u, rec_lane = vl & 63u;
     const float4 pt = B.p_time[v], nk = B.n_key[v];
     const V p = mk(pt.x, pt.y, pt.z);
     const uint32_t key = __float_as_uint(nk.w);
-    int cur_light = -1;
-    bool lit = false, brdf_done = false;
-    V ldir = mk(0, 0, 0), f_d = mk(0, 0, 0), f_s = mk(0, 0, 0);
-    float dist = 0.f, d2 = 0.f;
     unsigned ray = 0xffffffffu;
     float vis = 0.f;
-    for (int kl = 0; kl < kn; ++kl) {
-        const unsigned k = (unsigned)(k0 + kl);
-        const int li = light_of[k];
+    for (int kl = 0, kend; kl < kn; kl = kend) {   // light by light; the samples of a light are consecutive
+        const int li = light_of[k0 + kl];
         const rt_light &L = S.lights[li];
+        kend = min(kn, light_of[k_total + li] + L.samples - k0);
         if (defer != 0 && L.type == RT_LIGHT_SPHERE) {
             const rt_sphere &sph = S.spheres[L.sphere];
-            if (li != cur_light) {   // the light's first sample of the pass (uniform over the wave)
-                cur_light = li;
-                brdf_done = false;
-                lit = false;
-                if ((have >> kl) & 1ull) {
-                    const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, rec_lane);
-                    lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3])] != 0.f;
-                }
-                if (lit) sphere_light_geometry(sph, p, ldir, dist, d2);
+            bool lit = false;
+            if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u);
+                lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3]) + rec_lane] != 0.f;
             }
-            if (!lit) continue;
-            const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
-            const V rad = sphere_light_radiance(L, sph, ldir, d2, r1, r2);
-            if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
-            ++cnt.shadow;
-            if (!brdf_done) {
-                brdf_done = true;
-                const float4 vm = B.view_mat[v], kds = B.kd_slot[v], ksn = B.ks_n[v];
-                brdf_terms(__float_as_int(vm.w), ksn.w, mk(nk.x, nk.y, nk.z), ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z),
-                           mk(ksn.x, ksn.y, ksn.z), f_d, f_s);
-            }
+            if (__ballot(lit) == 0) continue;
+            V ldir = mk(0, 0, 0), f_d = mk(0, 0, 0), f_s = mk(0, 0, 0);
+            float dist = 0.f, d2 = 1.f;
+            if (lit) sphere_light_geometry(sph, p, ldir, dist, d2);
             const float lw = rt_div(1.0f, (float)L.samples);
-            c = add(c, scl(mul(f_d, rad), lw));
-            c = add(c, scl(mul(f_s, rad), lw));
-        } else if ((have >> kl) & 1ull) {
-            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, rec_lane);
+            bool brdf_done = false;
+            for (int ks = kl; ks < kend; ++ks) {
+                if (!lit) continue;
+                const unsigned k = (unsigned)(k0 + ks);
+                const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
+                const V rad = sphere_light_radiance(L, sph, ldir, d2, r1, r2);
+                if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
+                ++cnt.shadow;
+                if (!brdf_done) {
+                    brdf_done = true;
+                    const float4 vm = B.view_mat[v], kds = B.kd_slot[v], ksn = B.ks_n[v];
+                    brdf_terms(__float_as_int(vm.w), ksn.w, mk(nk.x, nk.y, nk.z), ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z),
+                               mk(ksn.x, ksn.y, ksn.z), f_d, f_s);
+                }
+                c = add(c, scl(mul(f_d, rad), lw));
+                c = add(c, scl(mul(f_s, rad), lw));
+            }
+            continue;
+        }
+        for (int ks = kl; ks < kend; ++ks) {
+            if (!((have >> ks) & 1ull)) continue;
+            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)ks, rec_lane);
             const float4 fd = Q.fd_ray[ri];
             if (__float_as_uint(fd.w) != ray) {
                 ray = __float_as_uint(fd.w);
@@ -924,9 +938,9 @@ __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront
         const unsigned vl = mine[on ? lane : 0u];
         const unsigned v = shard_base + vl;
         const float4 af = B.amb_first[v], w = B.weight[v];
-        const unsigned long long have = (unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w);
+        const unsigned long long have = (unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w);
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k0, kn, k_pad, defer, on ? have : 0ull, c, cnt);
+        c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k_total, k0, kn, k_pad, defer, on, on ? have : 0ull, c, cnt);
         if (on) finish(c, w, __float_as_int(B.kd_slot[v].w));
     };
     unsigned n_pending = 0;   // uniform over the wave
@@ -935,9 +949,21 @@ __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront
         const bool valid = vl < nv;
         const unsigned v = shard_base + (valid ? vl : vbase);
         const float4 af = B.amb_first[v], w = B.weight[v];
-        unsigned long long have = has_records ? ((unsigned long long)__float_as_uint(w.w) << 32 | __float_as_uint(af.w)) : 0ull;
-        if (record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) >= shadow_base + W.shadow_shard_entries) have = 0;
-        const bool full = valid && have != 0;
+        unsigned long long have = has_records ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
+        const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
+        if (!room) have = 0;
+        bool full = valid && have != 0;
+        if (defer != 0 && room) {   // `defer`: the pass holds deferred lights; is one of them visible from the vertex?
+            for (int kl = 0, kend; kl < kn; kl = kend) {
+                const int li = light_of[k0 + kl];
+                const rt_light &L = S.lights[li];
+                kend = min(kn, light_of[k_total + li] + L.samples - k0);
+                if (L.type != RT_LIGHT_SPHERE) continue;
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u);
+                const unsigned first_ray = __float_as_uint(((const float *)&W.shadow[gen & 1].fd_ray[ri])[3]);
+                if (valid && W.shadow[gen & 1].vis[first_ray + lane] != 0.f) full = true;
+            }
+        }
         if (valid && !full) finish(pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0), w, __float_as_int(B.kd_slot[v].w));
         const unsigned long long mask = __ballot(full);
         if (mask) {
@@ -1060,8 +1086,9 @@ struct rt_scene {
     Wavefront wf{};
     std::vector<void *> wf_allocations;
     unsigned *host_flags = nullptr;   // pinned: overflow flag read back per batch
-    int *light_of = nullptr;          // light-sample number -> light index
+    int *light_of = nullptr;          // [k_total] light-sample number -> light index, then [n_lights] light -> its first sample number
     int k_total = 0, k_pad = 1;
+    std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
     unsigned trace_blocks[2][2] = {{0, 0}, {0, 0}};   // resident workgroups of trace_kernel<ANY, COUNT>, a multiple of N_SHARDS
     // per-kernel timing (rt_set_profiling): every launch bracketed by two events on `stream`
@@ -1502,6 +1529,16 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         for (int i = 0; i < d->n_lights; ++i)
             for (int k = 0; k < d->lights[i].samples; ++k) light_of.push_back(i);
         s->k_total = (int)light_of.size();
+        {   // behind the table: the first sample number of every light
+            int first = 0;
+            for (int i = 0; i < d->n_lights; ++i) {
+                light_of.push_back(first);
+                first += d->lights[i].samples;
+            }
+        }
+        s->pass_has_emitter.assign((size_t)(s->k_total + 63) / 64, 0);
+        for (int k = 0; k < s->k_total; ++k)
+            if (d->lights[light_of[(size_t)k]].type == RT_LIGHT_SPHERE) s->pass_has_emitter[(size_t)k / 64] = 1;
         s->k_pad = 1;
         while (s->k_pad < s->k_total && s->k_pad < 64) s->k_pad <<= 1;
         if (upload<int>(light_of.data(), light_of.size(), &s->light_of)) {
@@ -1723,7 +1760,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                 }
                 launch_trace(s, lighting, true, grid, gen, 0);
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, 1, share_rays, s->stats);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
             }
             if (n_pass == 0 && !pt) {   // ambient only
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
