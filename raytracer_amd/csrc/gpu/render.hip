@@ -102,7 +102,7 @@ struct Wavefront {
     VertexBuf vtx[2];         // by generation parity: the direct lighting of generation g runs beside the
     ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
     unsigned shadow_shard_entries;   // shadow records per shard
-    float *accum;             // 3 floats per slot
+    float *accum;             // radiance sums per slot: three planes (r, g, b) of `capacity` floats
     unsigned *counters;       // [3 kinds][MAX_GENERATIONS + 1][N_SHARDS] entry counts, one 128-byte line each
     unsigned *overflow;       // set when a queue ran out of room
     unsigned shard_entries;   // path / vertex entries per shard
@@ -156,10 +156,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ void accum_add(float *accum, int slot, V v) {
-    unsafeAtomicAdd(accum + 3 * (size_t)slot + 0, v.x);
-    unsafeAtomicAdd(accum + 3 * (size_t)slot + 1, v.y);
-    unsafeAtomicAdd(accum + 3 * (size_t)slot + 2, v.z);
+// Float atomics run at the memory side in 64-byte requests: with one plane per colour, lanes whose slots are neighbours
+// share a request.
+__device__ __forceinline__ void accum_add(const Wavefront &W, int slot, V v) {
+    unsafeAtomicAdd(W.accum + (size_t)slot, v.x);
+    unsafeAtomicAdd(W.accum + (size_t)W.capacity + (size_t)slot, v.y);
+    unsafeAtomicAdd(W.accum + 2 * (size_t)W.capacity + (size_t)slot, v.z);
 }
 
 // The frame's ray and work counters: STAT_ROWS rows of STAT_WORDS 64-bit words, one row per 128-byte line; a
@@ -189,9 +191,9 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
         s = (int)(g / (unsigned)b.n_pixels);
         batch_pixel(b, (int)(g % (unsigned)b.n_pixels), i, j);
         valid = i < cam.resx && j < cam.resy;
-        W.accum[3 * (size_t)g] = 0.f;
-        W.accum[3 * (size_t)g + 1] = 0.f;
-        W.accum[3 * (size_t)g + 2] = 0.f;
+        W.accum[(size_t)g] = 0.f;
+        W.accum[(size_t)W.capacity + g] = 0.f;
+        W.accum[2 * (size_t)W.capacity + g] = 0.f;
     }
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned local = wave_append(valid, counter_of(W, Q_PATH, 0, shard));
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                 } else {
                     bgc = background(S, cam, d, !PT, pixelu, pixelv, c);
                 }
-                accum_add(W.accum, slot, mul(thr, bgc));
+                accum_add(W, slot, mul(thr, bgc));
             } else {
                 ++c.shaded;
                 const Surface sf = surface_of(S, h);
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     bool replace_all;
                     resolve_textures(S, sf, shade_p, m, kd, ks, kd_rr, replace_all, rep, c);
                     if (replace_all) {
-                        accum_add(W.accum, slot, mul(thr, rep));
+                        accum_add(W, slot, mul(thr, rep));
                     } else {
                         want_vertex = true;   // ambient + lights are summed by the gather kernel in calculate_color's order
                         v_p = shade_p;
@@ -538,13 +540,13 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                     resolve_textures(S, sf, p, m, kd, ks, kd_rr, replace_all, rep, c);
                     const uint32_t texels_resolve = c.texels - texels_before;
                     if (replace_all) {
-                        accum_add(W.accum, slot, mul(thr, rep));
+                        accum_add(W, slot, mul(thr, rep));
                     } else {
                         V emission = sf.kind == 0 ? mk(S.instances[sf.instance].emission)
                                                   : (sf.kind == 1 ? mk(S.spheres[sf.index].emission) : mk(0, 0, 0));
                         if (m.type != RT_MAT_REGULAR) {
                             if (!((float)depth < S.max_depth)) {
-                                accum_add(W.accum, slot, mul(thr, emission));   // specular surface at the depth limit keeps its emission only
+                                accum_add(W, slot, mul(thr, emission));   // specular surface at the depth limit keeps its emission only
                             } else if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
                                 V coef = mk(m.mirror);
                                 if (m.type == RT_MAT_CONDUCTOR) {
@@ -596,7 +598,7 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
                                 }
                             }
                         } else {
-                            accum_add(W.accum, slot, mul(thr, emission));
+                            accum_add(W, slot, mul(thr, emission));
                             float rr_prob = 1.0f;
                             bool alive = true;
                             if (cam.russian_roulette && depth >= cam.min_recursion_depth) {
@@ -931,7 +933,7 @@ __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront
     memset(&cnt, 0, sizeof cnt);
     auto finish = [&](V c, float4 w, int slot_scale) {
         if (slot_scale < 0) c = scl(c, 0.004f);
-        accum_add(W.accum, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
+        accum_add(W, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
     };
     auto evaluate = [&](unsigned n_ready) {   // the first n_ready (<= 64) collected vertices
         const bool on = lane < n_ready;
@@ -991,8 +993,8 @@ __global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch 
     if (i >= cam.resx || j >= cam.resy) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int s = 0; s < b.n_samples; ++s) {
-        const float *src = W.accum + 3 * ((size_t)s * b.n_pixels + pl);
-        float r = src[0], g = src[1], bl = src[2];
+        const float *src = W.accum + ((size_t)s * b.n_pixels + pl);
+        float r = src[0], g = src[(size_t)W.capacity], bl = src[2 * (size_t)W.capacity];
         if (cam.sample_max_val > 0.0f) {
             r = min_std(r, cam.sample_max_val);
             g = min_std(g, cam.sample_max_val);
@@ -1027,7 +1029,7 @@ __global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_
         if (prim <= -2) {
             shape = S.n_triangles + S.n_spheres + (-2 - prim);
         } else if (prim >= 0) {
-            const float4 p2 = S.prims[3 * (size_t)prim + 2];
+            const float4 p2 = S.prims[PRIM_STRIDE * (size_t)prim + 2];
             shape = __float_as_int(p2.z);
             id = __float_as_int(p2.w);
         }
@@ -1421,7 +1423,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         }
     }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
-    std::vector<float4> prims((size_t)d->n_bvh_prims * 3);
+    std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
     auto as_float = [](int v) {
         float f;
         memcpy(&f, &v, 4);
@@ -1437,15 +1439,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
                 e1[a] = t.c2[a] * 1000.0f - c1s[a];
                 e2[a] = t.c3[a] * 1000.0f - c1s[a];
             }
-            prims[3 * i] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
-            prims[3 * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+            prims[PRIM_STRIDE * i] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
+            prims[PRIM_STRIDE * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
             const rt_instance &in = d->instances[p.instance];
             const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
-            prims[3 * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), as_float(p.shape), as_float(in.ref_id));
+            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), as_float(p.shape), as_float(in.ref_id));
         } else {
-            prims[3 * i] = make_float4(0, 0, 0, 0);
-            prims[3 * i + 1] = make_float4(0, 0, 0, 0);
-            prims[3 * i + 2] = make_float4(0, as_float(-1 - (p.shape - d->n_triangles)), as_float(p.shape), as_float(123456));
+            prims[PRIM_STRIDE * i] = make_float4(0, 0, 0, 0);
+            prims[PRIM_STRIDE * i + 1] = make_float4(0, 0, 0, 0);
+            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(-1 - (p.shape - d->n_triangles)), as_float(p.shape), as_float(123456));
         }
     }
     std::vector<float4> inst((size_t)d->n_instances * 4);

@@ -87,6 +87,10 @@ constexpr int LDS_STACK = RT_LDS_STACK;
 constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
 constexpr int REF_POP = 0x40000000;
 constexpr int REF_IDLE = 0x40000001;
+#ifndef RT_PRIM_STRIDE
+#define RT_PRIM_STRIDE 4
+#endif
+constexpr int PRIM_STRIDE = RT_PRIM_STRIDE;   // float4 per leaf entry: 3 used; 4 keeps an entry inside one 64-byte block
 constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's placement index: the placement moves or transforms the ray
 
 // Box test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance.  The
@@ -237,11 +241,11 @@ __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const u
 // Leaf entry k against the ray; true with the distance in `tc` when the primitive reports a hit (t > eps).
 template <bool COUNT>
 __device__ __forceinline__ bool prim_test(const DevScene &S, int k, const RayState &r, float eps, float &tc, Counters &c) {
-    const float4 p2 = S.prims[3 * (size_t)k + 2];
+    const float4 p2 = S.prims[PRIM_STRIDE * (size_t)k + 2];
     const int inst = __float_as_int(p2.y);
     if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
         if (COUNT) ++c.tri;
-        const float4 p0 = S.prims[3 * (size_t)k], p1 = S.prims[3 * (size_t)k + 1];
+        const float4 p0 = S.prims[PRIM_STRIDE * (size_t)k], p1 = S.prims[PRIM_STRIDE * (size_t)k + 1];
         const V ro = mk(r.ox, r.oy, r.oz), rd = mk(r.dx, r.dy, r.dz);
         V oo = ro, dd = rd;
         if (inst & PRIM_XFORM_BIT) {
@@ -329,7 +333,7 @@ __device__ Surface surface_of(const DevScene &S, const Hit &h) {
         s.tcount = p.tex_count;
         return s;
     }
-    const float4 p2 = S.prims[3 * h.prim + 2];
+    const float4 p2 = S.prims[PRIM_STRIDE * (size_t)h.prim + 2];
     int inst = __float_as_int(p2.y);
     if (inst >= 0) {
         inst &= ~PRIM_XFORM_BIT;
