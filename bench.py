@@ -81,20 +81,25 @@ def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
     return {"value": so.total_rays / ms / 1e3, "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample, "ms": ms}
 
 
-def kernel_bytes(st):
-    """Algorithmic bytes per kernel class for one frame, from the frame's work counters.  Traversal: 32 B per node
-    visit, 36 B per triangle test, 64 B per sphere test, 24 B per plane test, 32 B ray read + 16 B hit write per ray.
-    Shading: 64 B material + 12 B framebuffer per shaded hit, 16 B per texel fetch.  Queue records at their stored
-    size: path 52 B, vertex 112 B, light-sample record 32 B, shadow ray 32 B + 4 B visibility."""
+def kernel_bytes(st, timed):
+    """Algorithmic bytes per kernel class for one frame.  `st`: the frame's work counters (counted frame, every light
+    sample evaluated and traced on its own), `timed`: the statistics of a timed frame (sphere emitters deferred: one
+    shadow ray per shading point, samples evaluated where it arrives).  Traversal: 32 B per node visit, 36 B per
+    triangle test, 64 B per sphere test, 24 B per plane test, 32 B ray read + 16 B hit write per ray.  Shading: 64 B
+    material + 12 B framebuffer per shaded hit, 16 B per texel fetch.  Queue records at their stored size: path 52 B,
+    vertex 112 B, shadow ray 32 B + 4 B visibility."""
     camera = st.primary_rays
     paths = st.primary_rays + st.secondary_rays
+    rays = timed.shadow_rays_traced
     return {
         "generate": 64 * camera,
         "trace_closest": st.traversal_bytes(False),
         "shade": 60 * paths + 76 * st.shaded_hits + 16 * st.texel_fetches + 112 * st.shaded_hits + 52 * st.secondary_rays,
-        "light_setup": 112 * st.shaded_hits + 32 * st.shadow_rays + 32 * st.shadow_rays_traced,
-        "trace_any": st.traversal_bytes(True) - 12 * st.shadow_rays_traced,
-        "light_gather": 64 * st.shaded_hits + 36 * st.shadow_rays + 12 * st.shaded_hits,
+        # deferred emitters: position in, ray out; the gather reads 32 B of every vertex, the visibility, the whole
+        # vertex where the emitter is visible (bounded here by every vertex), and adds 12 B to the slot
+        "light_setup": 16 * st.shaded_hits + 32 * rays,
+        "trace_any": (st.traversal_bytes(True) - 12 * st.shadow_rays_traced) * (rays / max(1, st.shadow_rays_traced)),
+        "light_gather": (32 + 4 + 112 + 12) * st.shaded_hits,
         "resolve": 12 * camera + 12 * camera,
     }
 
@@ -225,12 +230,10 @@ def main():
         # dominant kernel = the kernel class with the largest device time in the timed steps
         name = max(ktimes, key=lambda k: ktimes[k][1])
         launches, total_ms = ktimes[name]
-        per_frame = kernel_bytes(cs)   # algorithmic bytes of each kernel class in one frame
+        per_frame = kernel_bytes(cs, stats)   # algorithmic bytes of each kernel class in one frame
         launches_per_frame = launches / args.steps
         bytes_per_launch = per_frame[name] / launches_per_frame
         ms_per_launch = total_ms / launches
-        if name == "trace_any":   # the counted frame traversed every sample's ray; the timed frames shared identical ones
-            bytes_per_launch *= (stats.shadow_rays_traced / max(1, cs.shadow_rays_traced))
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
         line = {
             "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
