@@ -93,3 +93,42 @@ def test_shared_shadow_rays_change_nothing_but_the_work(name, scene_dir):
         assert st_shared.shadow_rays_traced < st_each.shadow_rays and st_shared.shadow_rays < st_each.shadow_rays
     err = np.abs(shared - each) / np.maximum(np.abs(each), 1 / 255)
     assert err.max() <= 1e-5
+
+
+def many_lights_scene(out_dir, n_emitters=5):
+    """More than 64 light samples per shading point (two passes of the lighting kernels), kinds mixed: a point light,
+    an area light, a mesh emitter and sphere emitters with 16 samples each, so that one emitter's samples straddle the
+    pass boundary whatever order the lights are numbered in."""
+    mats = [GS.MAT_DIFFUSE, {"_id": "2", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0 0 0", "SpecularReflectance": "0 0 0"},
+            {"_id": "3", "AmbientReflectance": "1 1 1", "DiffuseReflectance": "0.3 0.6 0.8", "SpecularReflectance": "0.4 0.4 0.4", "PhongExponent": "25"}]
+    centres = [(-2.0 + 1.0 * k, 2.2 + 0.3 * (k % 2), 0.5 + 0.4 * k) for k in range(n_emitters)]
+    verts = GS.GROUND + "  -1 0.6 0.3  1.1 0.5 -0.2  -2.5 2.5 -1  -1.5 2.5 -1  -1.5 2.5 0  -2.5 2.5 0  " + GS.verts_str(centres)
+    objects = {"Mesh": {"_id": "1", "Material": "1", "Faces": {"_data": GS.GROUND_FACES}},
+               "LightMesh": {"_id": "2", "Material": "2", "Radiance": "30 24 18", "Faces": {"_data": "7 9 8  7 10 9"}},
+               "Sphere": [{"_id": "1", "Material": "3", "Center": "5", "Radius": "0.6"},
+                          {"_id": "2", "Material": "1", "Center": "6", "Radius": "0.5"}],
+               "LightSphere": [{"_id": str(k + 1), "Material": "2", "Center": str(11 + k), "Radius": "0.25",
+                                "Radiance": f"{20 + 5 * k} {22 + 3 * k} {30 - 2 * k}"} for k in range(n_emitters)]}
+    lights = {"AmbientLight": "5 5 5", "PointLight": {"_id": "1", "Position": "3 5 4", "Intensity": "2000 2000 2000"},
+              "AreaLight": {"_id": "1", "Position": "1 4 2", "Normal": "0 -1 0", "Size": "1.5", "Radiance": "15 15 15"}}
+    sc = GS.scene(GS.camera("many_lights.png", res=(64, 48), NumSamples="4"), lights, mats, verts, objects)
+    return GS.dump(out_dir, "many_lights", sc)
+
+
+def test_many_lights_two_passes_all_paths_agree(scene_dir):
+    """The deferred-emitter path, the counted path (every sample on its own) and the CPU oracle give the same image for
+    a scene whose light samples need two passes and mix deferred and recorded lights in one shading point."""
+    from oracle_lib import Oracle
+    sc = R.Scene(many_lights_scene(scene_dir))
+    assert sum(sc.desc.lights[i].samples for i in range(sc.desc.n_lights)) > 128     # three passes
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    fast, st_fast = ren.render(cam)
+    ren.set_counters(True)
+    counted, st_counted = ren.render(cam)
+    want, st_oracle = Oracle(sc).render(cam)
+    assert st_counted.shadow_rays == st_oracle.shadow_rays and st_counted.shadow_rays > 40 * st_counted.primary_rays
+    assert st_fast.shadow_rays_traced < st_counted.shadow_rays_traced
+    floor = 1 / 255
+    assert (np.abs(counted - want) / np.maximum(np.abs(want), floor)).max() <= 1e-5
+    assert (np.abs(fast - counted) / np.maximum(np.abs(counted), floor)).max() <= 1e-5
