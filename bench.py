@@ -57,6 +57,7 @@ def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
     cam = sc.camera(0)
     # ray count of the sample: from the device counters of the same sample (the reference has no ray counter)
     ren = R.Renderer(sc)
+    ren.set_counters(True)   # counted mode: rays exactly as the reference's algorithm casts them
     _, st = ren.render(cam)
     rays = st.total_rays
     ren.close()
