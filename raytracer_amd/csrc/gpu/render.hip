@@ -704,12 +704,19 @@ __global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc c
 // Light samples are numbered over all lights (`light_of` maps a number to its light); a pass covers 64 of them.
 // Records are stored per block of 64 vertices, sample-major: record (block, sample, lane), so that both kernels
 // read and write 64 consecutive records at a time.
-__device__ __forceinline__ unsigned record_index(unsigned shadow_base, unsigned vbase, unsigned k_pad, unsigned kl, unsigned lane) {
-    return shadow_base + (vbase * k_pad + kl * 64u) + lane;   // vbase is a multiple of 64
+__device__ __forceinline__ unsigned record_index(unsigned shadow_base, unsigned vbase, unsigned k_pad, unsigned slot, unsigned lane) {
+    return shadow_base + (vbase * k_pad + slot * 64u) + lane;   // vbase is a multiple of 64, slot < k_pad
+}
+// The record slot of light sample k (number kl of its pass).  With every sample recorded it is kl; with deferred emitters
+// only the other samples and one entry per emitter need a slot, and a table behind `light_of` numbers those per pass, so
+// that a vertex takes k_pad = a few slots instead of 16 or 64.
+__device__ __forceinline__ unsigned record_slot(const int *__restrict__ light_of, int slot_table, unsigned k, int kl) {
+    return slot_table >= 0 ? (unsigned)light_of[slot_table + (int)k] : (unsigned)kl;
 }
 
 __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
-                                                           int k_total, int k_pad, int share_rays, unsigned long long *__restrict__ stats) {
+                                                           int k_total, int k_pad, int slot_table, int share_rays,
+                                                           unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
     unsigned nv = *counter_of(W, Q_VERTEX, gen, shard);
@@ -769,7 +776,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                         W.shadow[gen & 1].o_dist[ray_index] = make_float4(so.x, so.y, so.z, kept_dist);
                         W.shadow[gen & 1].d_time[ray_index] = make_float4(kept_ldir.x, kept_ldir.y, kept_ldir.z, pt.w);
                         if (lane == 0)
-                            ((float *)&W.shadow[gen & 1].fd_ray[record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u)])[3] = __uint_as_float(ray_index);
+                            ((float *)&W.shadow[gen & 1].fd_ray[record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, k, kl), 0u)])[3] = __uint_as_float(ray_index);
                     }
                 }
                 prev_light = -1;
@@ -832,7 +839,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                     W.shadow[gen & 1].o_dist[ray_index] = make_float4(so.x, so.y, so.z, dist);
                     W.shadow[gen & 1].d_time[ray_index] = make_float4(ldir.x, ldir.y, ldir.z, pt.w);
                 }
-                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, lane);
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, k, kl), lane);
                 W.shadow[gen & 1].fd_ray[ri] = make_float4(fd.x, fd.y, fd.z, __uint_as_float(ray_index));
                 W.shadow[gen & 1].fs_[ri] = make_float4(fs.x, fs.y, fs.z, 0.f);
                 prev_ray = ray_index;
@@ -850,8 +857,8 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
 // Adds the direct lighting of one vertex (lane-local): every light sample of the pass in sample order.  A sample of a
 // deferred sphere light is evaluated here when the light's ray arrived; any other sample contributes its record.
 __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W, int gen, unsigned v, unsigned vl, unsigned shadow_base,
-                                           const int *__restrict__ light_of, int k_total, int k0, int kn, int k_pad, int defer, bool active,
-                                           unsigned long long have, V c, Counters &cnt) {
+                                           const int *__restrict__ light_of, int k_total, int k0, int kn, int k_pad, int slot_table, int defer,
+                                           bool active, unsigned long long have, V c, Counters &cnt) {
     const VertexBuf &B = W.vtx[gen & 1];
     const ShadowQueue &Q = W.shadow[gen & 1];
     const unsigned vbase = vl & ~63u, rec_lane = vl & 63u;
@@ -868,7 +875,7 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
             const rt_sphere &sph = S.spheres[L.sphere];
             bool lit = false;
             if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
-                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u);
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
                 lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3]) + rec_lane] != 0.f;
             }
             if (__ballot(lit) == 0) continue;
@@ -897,7 +904,7 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
         }
         for (int ks = kl; ks < kend; ++ks) {
             if (!((have >> ks) & 1ull)) continue;
-            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)ks, rec_lane);
+            const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + ks), ks), rec_lane);
             const float4 fd = Q.fd_ray[ri];
             if (__float_as_uint(fd.w) != ray) {
                 ray = __float_as_uint(fd.w);
@@ -917,7 +924,8 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
 // however the lit and the shadowed vertices are mixed.
 constexpr int GATHER_QUEUE = 128;
 __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of, int k_total,
-                                                            int k_pad, int has_records, int defer, unsigned long long *__restrict__ stats) {
+                                                            int k_pad, int slot_table, int has_records, int defer,
+                                                            unsigned long long *__restrict__ stats) {
     __shared__ unsigned pending[4][GATHER_QUEUE];
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries, shadow_base = shard * W.shadow_shard_entries;
@@ -942,7 +950,7 @@ __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront
         const float4 af = B.amb_first[v], w = B.weight[v];
         const unsigned long long have = (unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w);
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
-        c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k_total, k0, kn, k_pad, defer, on, on ? have : 0ull, c, cnt);
+        c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k_total, k0, kn, k_pad, slot_table, defer, on, on ? have : 0ull, c, cnt);
         if (on) finish(c, w, __float_as_int(B.kd_slot[v].w));
     };
     unsigned n_pending = 0;   // uniform over the wave
@@ -961,7 +969,7 @@ __global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront
                 const rt_light &L = S.lights[li];
                 kend = min(kn, light_of[k_total + li] + L.samples - k0);
                 if (L.type != RT_LIGHT_SPHERE) continue;
-                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)kl, 0u);
+                const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
                 const unsigned first_ray = __float_as_uint(((const float *)&W.shadow[gen & 1].fd_ray[ri])[3]);
                 if (valid && W.shadow[gen & 1].vis[first_ray + lane] != 0.f) full = true;
             }
@@ -1088,8 +1096,10 @@ struct rt_scene {
     Wavefront wf{};
     std::vector<void *> wf_allocations;
     unsigned *host_flags = nullptr;   // pinned: overflow flag read back per batch
-    int *light_of = nullptr;          // [k_total] light-sample number -> light index, then [n_lights] light -> its first sample number
-    int k_total = 0, k_pad = 1;
+    int *light_of = nullptr;          // [k_total] light-sample number -> light index, [n_lights] light -> its first sample number, [k_total] slot table
+    int k_total = 0, k_pad = 1;       // light samples per shading point; record slots per vertex with every sample recorded
+    int k_pad_deferred = 1;           // record slots per vertex with sphere emitters deferred (see record_slot)
+    int slot_table = -1;              // offset of the deferred-mode slot table in light_of
     std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
     unsigned trace_blocks[2][2] = {{0, 0}, {0, 0}};   // resident workgroups of trace_kernel<ANY, COUNT>, a multiple of N_SHARDS
@@ -1145,26 +1155,30 @@ static void harvest_timers(rt_scene *s) {
 
 constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
 
-// Upper bound of entries per path queue / vertex buffer / accumulator (RT_WAVEFRONT_CAPACITY overrides).  One
-// entry costs ~2.5 KB of HBM, most of it the two sets of 16 shadow records; the default of 48 Mi entries is 121 GB
-// of the 288 GB.  Large batches matter: every kernel of a batch ends with a tail in which the last rays finish on a
-// mostly idle chip, and the fewer batches a frame has, the fewer tails it pays for.
-static unsigned wavefront_capacity() {
+// Upper bound of entries per path queue / vertex buffer / accumulator.  An entry costs 348 bytes plus 136 bytes per
+// shadow slot (`shadow_mult` slots per entry: rays and light-sample records of one vertex in one lighting pass, both
+// generations' sets); the default is what fits 128 GB of the 288 GB -- 264 Mi entries at one slot per vertex, 50 Mi at
+// sixteen -- and RT_WAVEFRONT_CAPACITY overrides it.  Large batches matter: every kernel of a batch ends with a tail in
+// which the last rays finish on a mostly idle chip, and the fewer batches a frame has, the fewer tails it pays for
+// (4K / 64 spp frame of the 1M-triangle scene: 948 ms at 12 Mi entries, 857 at 24 Mi, 803 at 48 Mi).
+static unsigned wavefront_capacity(unsigned shadow_mult) {
+    const unsigned long long unit = N_SHARDS * 256;
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
-        if (v >= 65536 && v <= (1l << 27)) return (unsigned)v / (N_SHARDS * 256) * (N_SHARDS * 256);
+        if (v >= 65536 && v <= (1l << 28)) return (unsigned)((unsigned long long)v / unit * unit);
     }
-    return 3u << 24;
+    const unsigned long long budget = 128000000000ull, per_entry = 348ull + 136ull * shadow_mult;
+    return (unsigned)(std::min<unsigned long long>(budget / per_entry, 1ull << 28) / unit * unit);
 }
 
 // Allocates the wavefront state for `cap` entries; on failure everything allocated so far is released.
-static int allocate_wavefront(rt_scene *s, unsigned cap, Wavefront &W) {
+static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, Wavefront &W) {
     auto alloc = [&](void **p, size_t bytes) -> bool {
         if (hipMalloc(p, bytes) != hipSuccess) return false;
         s->wf_allocations.push_back(*p);
         return true;
     };
-    const size_t scap = (size_t)cap * 16u;   // shadow records: up to 16 light samples per vertex at full path capacity
+    const size_t scap = (size_t)cap * shadow_mult;   // shadow rays and records: `shadow_mult` per vertex at full path capacity
     bool ok = true;
     for (int k = 0; k < 2 && ok; ++k) {
         ok = alloc((void **)&W.q[k].o_time, (size_t)cap * 16) && alloc((void **)&W.q[k].d_key, (size_t)cap * 16) &&
@@ -1229,18 +1243,22 @@ static bool park_wavefront(rt_scene *s) {
     return true;
 }
 
-// Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries; grows, never shrinks.  When
-// the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
-static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
+// Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries and `shadow_floor` shadow slots
+// (what one batch of the smallest size needs); grows, never shrinks.  A new state gets `shadow_mult` shadow slots per
+// entry.  When the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
+static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned shadow_mult, unsigned long long shadow_floor) {
     // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
     const unsigned long long unit = N_SHARDS * 256;
     wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
-    unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity());
-    if (s->wf.capacity >= cap) return 0;
+    unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity(shadow_mult));
+    auto enough = [&](const Wavefront &W) {
+        return W.capacity >= cap && (unsigned long long)W.shadow_shard_entries * N_SHARDS >= std::min<unsigned long long>(shadow_floor, (unsigned long long)cap * shadow_mult);
+    };
+    if (enough(s->wf)) return 0;
     if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
     if (!s->wf.capacity) {
         adopt_idle_wavefront(s);
-        if (s->wf.capacity >= cap) return 0;
+        if (enough(s->wf)) return 0;
     }
     HIP_OK(hipStreamSynchronize(s->stream));
     HIP_OK(hipStreamSynchronize(s->stream2));
@@ -1249,7 +1267,7 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted) {
     s->wf = Wavefront{};
     for (;;) {
         Wavefront W{};
-        if (allocate_wavefront(s, cap, W) == 0) {
+        if (allocate_wavefront(s, cap, shadow_mult, W) == 0) {
             s->wf = W;
             return 0;
         }
@@ -1543,6 +1561,28 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             if (d->lights[light_of[(size_t)k]].type == RT_LIGHT_SPHERE) s->pass_has_emitter[(size_t)k / 64] = 1;
         s->k_pad = 1;
         while (s->k_pad < s->k_total && s->k_pad < 64) s->k_pad <<= 1;
+        {   // record slots with deferred emitters: per pass, one per other sample and one per emitter
+            s->slot_table = (int)light_of.size();
+            int most = 1;
+            for (int k0 = 0; k0 < s->k_total; k0 += 64) {
+                int next = 0, emitter = -1, emitter_slot = 0;
+                for (int k = k0; k < std::min(s->k_total, k0 + 64); ++k) {
+                    const int li = light_of[(size_t)k];
+                    if (d->lights[li].type == RT_LIGHT_SPHERE) {
+                        if (li != emitter) {
+                            emitter = li;
+                            emitter_slot = next++;
+                        }
+                        light_of.push_back(emitter_slot);
+                    } else {
+                        light_of.push_back(next++);
+                    }
+                }
+                most = std::max(most, next);
+            }
+            s->k_pad_deferred = 1;
+            while (s->k_pad_deferred < most) s->k_pad_deferred <<= 1;
+        }
         if (upload<int>(light_of.data(), light_of.size(), &s->light_of)) {
             rt_scene_destroy(s);
             return 10;
@@ -1667,7 +1707,16 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     // queue growth bound per camera sample: splitting fans out at depth 0, dielectrics may double per bounce
     unsigned growth = (unsigned)(pt && cam->splitting_factor > 1 ? cam->splitting_factor : 1) * (s->has_dielectric ? 2u : 1u);
     // room for the whole shard in one batch (plus the slack the batch planner keeps), as far as the bound allows
-    if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024)) return rc;
+    // Identical shadow rays of a vertex are traced once and sphere emitters are evaluated after their ray.  With the
+    // work counters on, every light sample is evaluated and traced on its own so that the counts are those of the
+    // reference's loop (src/ray_trace.cpp:182-241).
+    const char *share_env = getenv("RT_SHARE_SHADOW_RAYS");   // "0": as with the counters on (for A/B measurements)
+    const int share_rays = (!(share_env && atoi(share_env) == 0) && !s->counters) ? 1 : 0;
+    const unsigned slots_per_vertex = (unsigned)(share_rays ? s->k_pad_deferred : s->k_pad);   // shadow slots of a vertex in one pass
+    const int slot_table = share_rays ? s->slot_table : -1;
+    if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex,
+                                  1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024))
+        return rc;
     const Wavefront &W = s->wf;
     if ((unsigned long long)n_samples * 1024ull > W.capacity) {
         g_error = "NumSamples too large for the wavefront capacity (set RT_WAVEFRONT_CAPACITY)";
@@ -1703,17 +1752,13 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         s->lit.push_back(b);
     }
-    // Identical shadow rays of a vertex are traced once.  With the work counters on, every light sample's ray is
-    // traced on its own so that the counts are those of the reference's loop (src/ray_trace.cpp:182-241).
-    const char *share_env = getenv("RT_SHARE_SHADOW_RAYS");   // "0" traces every sample's ray (for A/B measurements)
-    const int share_rays = (!(share_env && atoi(share_env) == 0) && !s->counters) ? 1 : 0;
     static const bool one_stream = getenv("RT_ONE_STREAM") != nullptr;   // diagnostic: kernel times without overlap
     hipStream_t lighting = one_stream ? s->stream : s->stream2;
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
         // shards fill unevenly once paths branch or die: plan for 3/4 of the room
-        unsigned long long slots_max = std::min<unsigned long long>(W.capacity, (unsigned long long)W.shadow_shard_entries * N_SHARDS / (unsigned)s->k_pad) / growth;
+        unsigned long long slots_max = std::min<unsigned long long>(W.capacity, (unsigned long long)W.shadow_shard_entries * N_SHARDS / slots_per_vertex) / growth;
         if (growth > 1 || pt) slots_max = slots_max * 3 / 4;
         long long per_tile = 1024ll * n_samples;
         int tiles_now = (int)std::min<long long>(n_owned - tile, std::max<long long>(1, (long long)slots_max / per_tile));
@@ -1758,15 +1803,15 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                 {
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
-                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, share_rays, s->stats);
+                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
                 }
                 launch_trace(s, lighting, true, grid, gen, 0);
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, s->k_pad, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
             }
             if (n_pass == 0 && !pt) {   // ambient only
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, 0, 0, s->stats);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, -1, 0, 0, s->stats);
             }
             HIP_OK(hipEventRecord(s->lit[gen], lighting));
         }
@@ -1826,7 +1871,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     HIP_OK(hipSetDevice(s->device));
     const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
     const int total_tiles = tiles_x * tiles_y;
-    if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull)) return rc;
+    if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull, 1, 0)) return rc;
     const Wavefront &W = s->wf;
     const size_t n = (size_t)cam->resx * cam->resy;
     int32_t *d_shape = nullptr, *d_id = nullptr;
