@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "pt1m_4k_256spp"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-frames-only", action="store_true",
+                    help="profiling runs: skip the counted frame and the frame without ray sharing (their launches would mix "
+                         "into the per-kernel averages); the line then carries the timing only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank path on a single GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -198,6 +201,16 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = ren.kernel_times()
     ren.set_profiling(False)
+
+    if args.timed_frames_only:
+        if rank == 0:
+            print(json.dumps({"note": "timed frames only (profiling run)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed * 1e3 / args.steps, "config": {"workload": args.workload},
+                              "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()},
+                              "launches_per_frame": {k: v[0] / args.steps for k, v in ktimes.items()}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # one extra, untimed frame with the work counters on: algorithmic bytes for the roofline.  In this mode every
     # light sample's shadow ray is traversed on its own, which is also the frame time without ray sharing.

@@ -1160,7 +1160,7 @@ constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STR
 // generations' sets); the default is what fits 128 GB of the 288 GB -- 264 Mi entries at one slot per vertex, 50 Mi at
 // sixteen -- and RT_WAVEFRONT_CAPACITY overrides it.  Large batches matter: every kernel of a batch ends with a tail in
 // which the last rays finish on a mostly idle chip, and the fewer batches a frame has, the fewer tails it pays for
-// (4K / 64 spp frame of the 1M-triangle scene: 948 ms at 12 Mi entries, 857 at 24 Mi, 803 at 48 Mi).
+// (4K / 64 spp frame of the 1M-triangle scene: 948 ms at 12 Mi entries, 857 at 24 Mi, 803 at 48 Mi, 775 at 96 Mi, 740 at 264 Mi).
 static unsigned wavefront_capacity(unsigned shadow_mult) {
     const unsigned long long unit = N_SHARDS * 256;
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {

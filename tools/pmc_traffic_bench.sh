@@ -2,8 +2,8 @@
 # one frame of the default benchmark workload.  Writes gpurun_out/pmc_traffic_bench.json.
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_bfetch gpurun_out/pmc_bwrite
-timeout -s KILL 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_bfetch -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_bfetch.log 2>&1 || { echo fetch pass failed; tail -3 gpurun_out/pmc_bfetch.log; exit 1; }
-timeout -s KILL 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_bwrite -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_bwrite.log 2>&1 || { echo write pass failed; tail -3 gpurun_out/pmc_bwrite.log; exit 1; }
+timeout -s KILL 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_bfetch -o p -- python3 bench.py --steps 1 --warmup 0 --timed-frames-only > gpurun_out/pmc_bfetch.log 2>&1 || { echo fetch pass failed; tail -3 gpurun_out/pmc_bfetch.log; exit 1; }
+timeout -s KILL 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_bwrite -o p -- python3 bench.py --steps 1 --warmup 0 --timed-frames-only > gpurun_out/pmc_bwrite.log 2>&1 || { echo write pass failed; tail -3 gpurun_out/pmc_bwrite.log; exit 1; }
 python3 - <<'PY'
 import csv, collections, json, re, os
 out = {}
@@ -23,7 +23,7 @@ for name, path in (("FETCH_SIZE", "gpurun_out/pmc_bfetch/p_counter_collection.cs
 for k, v in out.items():
     # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads count double; WRITE_SIZE is exact
     v["traffic_bytes_per_launch"] = 1024.0 * (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0))
-json.dump({"command": "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline", "workload": "pt1m_4k_256spp", "kernels": out},
+json.dump({"command": "python3 bench.py --steps 1 --warmup 0 --timed-frames-only", "workload": "pt1m_4k_256spp", "kernels": out},
           open("gpurun_out/pmc_traffic_bench.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
