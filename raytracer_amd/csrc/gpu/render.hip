@@ -52,8 +52,8 @@ thread_local std::string g_error;
 //   repeat    closest   closest-hit BVH traversal of every queued path       -> hit records
 //             shade     material / texture / emission / roulette; appends direct-lighting work
 //                       (vertex records) and child paths, compacted with wave ballots -> path queue 1
-//             direct    one lane per (vertex, light sample): light sampling, any-hit shadow
-//                       traversal, BRDF, fixed-order reduction over the vertex's lanes
+//             direct    per vertex: shadow rays and light-sample records (light_setup), any-hit shadow
+//                       traversal, then the sum over the light samples in sample order (light_gather)
 //   resolve   per pixel: clamp each sample, sum the samples in index order, divide
 // The recursion of the reference (trace_rec / path_trace) becomes the loop over queue generations; a
 // path carries its throughput, so the order in which paths are processed does not change what is
@@ -90,7 +90,8 @@ struct ShadowQueue {
     float4 *o_dist;     // shadow-ray origin.xyz, distance to the light sample
     float4 *d_time;     // direction.xyz, ray time
     float *vis;         // visibility, written by the any-hit trace
-    // one record per light sample with non-zero incident radiance
+    // one record per recorded light sample with non-zero incident radiance; for a deferred emitter, .w of the record of
+    // a block's lane 0 holds the index of the block's first ray to that emitter (see light_setup_kernel)
     float4 *fd_ray;     // diffuse term x radiance x 1/samples .xyz, bits(index of the sample's ray)
     float4 *fs_;        // specular term x radiance x 1/samples .xyz
 };
@@ -101,7 +102,7 @@ struct Wavefront {
     int *hit_prim;
     VertexBuf vtx[2];         // by generation parity: the direct lighting of generation g runs beside the
     ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
-    unsigned shadow_shard_entries;   // shadow records per shard
+    unsigned shadow_shard_entries;   // shadow rays, and light-sample records, per shard
     float *accum;             // radiance sums per slot: three planes (r, g, b) of `capacity` floats
     unsigned *counters;       // [3 kinds][MAX_GENERATIONS + 1][N_SHARDS] entry counts, one 128-byte line each
     unsigned *overflow;       // set when a queue ran out of room
