@@ -251,8 +251,12 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
     __shared__ uint2 stack_lds[LDS_STACK * 256];
+    __shared__ float4 top_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 1];
     uint2 *lds = stack_lds + threadIdx.x;
     uint2 spill[SPILL_STACK];
+    const int n_top = TOP_NODES > 0 ? min(S.n_top, TOP_NODES) : 0;
+    for (int i = threadIdx.x; i < 4 * n_top; i += 256) top_nodes[i] = S.nodes[i];
+    __syncthreads();
     const int shard = blockIdx.x % N_SHARDS;
     unsigned *ctr = counter_of(W, ANY ? Q_SHADOW : Q_PATH, gen, shard);
     const unsigned room = ANY ? W.shadow_shard_entries : W.shard_entries;
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         const unsigned long long at_leaf = __ballot(r.cur < 0);
         const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
         if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) {
-            if ((unsigned)r.cur < (unsigned)REF_POP) node_step<COUNT>(S, r, lds, spill, c);
+            if ((unsigned)r.cur < (unsigned)REF_POP) node_step<COUNT>(S, r, lds, spill, top_nodes, n_top, c);
         } else if (n_leaf) {
             if (r.cur < 0) {
                 const int k = r.cur & 0xffffff;
@@ -1403,10 +1407,39 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     std::vector<float4> nodes;
     int root_ref = 0;
     {
+        // Order of the records: the top of the tree breadth-first (the first TOP_NODES interior nodes a breadth-first
+        // walk meets; the trace kernel keeps them in LDS), then every subtree below depth-first (a node's left child
+        // next to it, a small subtree in a few cache lines).
         std::vector<int> interior_index(d->n_bvh_nodes, -1);
         int n_interior = 0;
-        for (int i = 0; i < d->n_bvh_nodes; ++i)
-            if (d->bvh_nodes[i].n_prims == 0) interior_index[i] = n_interior++;
+        {
+            std::vector<int> walk, below;
+            if (d->n_bvh_nodes > 0 && d->bvh_nodes[0].n_prims == 0) walk.push_back(0);
+            for (size_t at = 0; at < walk.size(); ++at) {
+                const int i = walk[at];
+                if (n_interior >= TOP_NODES) {
+                    below.push_back(i);
+                    continue;
+                }
+                interior_index[i] = n_interior++;
+                const int kids[2] = {i + 1, d->bvh_nodes[i].offset};
+                for (int kid : kids)
+                    if (d->bvh_nodes[kid].n_prims == 0) walk.push_back(kid);
+            }
+            s->dev.n_top = n_interior;
+            std::vector<int> stack;
+            for (int root : below) {
+                stack.push_back(root);
+                while (!stack.empty()) {
+                    const int i = stack.back();
+                    stack.pop_back();
+                    interior_index[i] = n_interior++;
+                    const int left = i + 1, right = d->bvh_nodes[i].offset;
+                    if (d->bvh_nodes[right].n_prims == 0) stack.push_back(right);
+                    if (d->bvh_nodes[left].n_prims == 0) stack.push_back(left);
+                }
+            }
+        }
         bool ok = true;
         auto ref_of = [&](int i) -> int {
             const rt_bvh_node &n = d->bvh_nodes[i];

@@ -45,6 +45,7 @@ struct DevScene {
     const rt_light *lights;
     int n_triangles, n_spheres, n_planes, n_lights, n_nodes;
     int root_ref;
+    int n_top;   // the first n_top node records are the top of the tree in breadth-first order (kept in LDS by the trace kernel)
     float root_min[3], root_max[3];
     float ieps, seps, max_depth;
     float ambient[3], bg[3];
@@ -81,7 +82,7 @@ struct Hit {
 //   REF_POP              take the next node from the stack
 //   REF_IDLE             no ray
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12
+#define RT_LDS_STACK 11
 #endif
 constexpr int LDS_STACK = RT_LDS_STACK;
 constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
@@ -192,10 +193,25 @@ __device__ __forceinline__ void stack_push(RayState &r, uint2 *lds, uint2 *spill
 
 // One interior node: both child boxes, near child next, far child pushed.  `lds` is this lane's column of a
 // __shared__ uint2 array laid out [LDS_STACK][STACK_STRIDE].
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 127
+#endif
+constexpr int TOP_NODES = RT_TOP_NODES;   // node records a workgroup of the trace kernel keeps in LDS (0: none).  Measured, closest-hit
+// time of a 4K / 64 spp frame: none 384 ms, 31: 379, 63: 375, 127 or more: 369 -- as long as stack and records stay under 31 KB,
+// beyond which only four workgroups fit a CU (426 ms)
+
+// `top`: the workgroup's LDS copy of the first `n_top` node records (the top levels of the tree, which every ray walks);
+// records read from it do not go through the vector cache, whose lookups are what bounds the traversal.
 template <bool COUNT>
-__device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, Counters &c) {
-    const float4 *np = S.nodes + 4 * (size_t)r.cur;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+__device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, const float4 *top, int n_top, Counters &c) {
+    float4 n0, n1, n2, n3;
+    if (TOP_NODES > 0 && r.cur < n_top) {
+        const float4 *np = top + 4 * r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    } else {
+        const float4 *np = S.nodes + 4 * (size_t)r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    }
     const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
     float tl, tr;
     bool pl, pr;
