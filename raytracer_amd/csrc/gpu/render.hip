@@ -387,7 +387,15 @@ __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard,
 // ---- shade: the hit-side half of trace_rec (src/ray_trace.cpp:646-869) / path_trace (:871-1139) ------------------
 // Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
 template <bool PT>
-__global__ void __launch_bounds__(256) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
+// waves per SIMD the register allocation aims at, measured (4K / 64 spp frame): shade 3: 86 ms, 4: 81, 5: 106 (spills);
+// gather 3: 95 ms, 6: 90, 7: 103
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+#ifndef RT_GATHER_WAVES
+#define RT_GATHER_WAVES 6
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries;
     unsigned count = *counter_of(W, Q_PATH, gen, shard);
@@ -928,7 +936,7 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
 // spot; the others are collected per wave and evaluated 64 at a time, so that the lanes of the expensive part are all busy
 // however the lit and the shadowed vertices are mixed.
 constexpr int GATHER_QUEUE = 128;
-__global__ void __launch_bounds__(256) light_gather_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of, int k_total,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES))) light_gather_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of, int k_total,
                                                             int k_pad, int slot_table, int has_records, int defer,
                                                             unsigned long long *__restrict__ stats) {
     __shared__ unsigned pending[4][GATHER_QUEUE];
