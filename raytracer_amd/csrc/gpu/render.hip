@@ -8,7 +8,7 @@
 //
 // Execution shape: a wavefront pipeline.  A frame is rendered in batches of camera samples; per batch the paths
 // advance one generation at a time through generate -> trace (closest hit) -> shade, and the vertices of a
-// generation are lit by light_setup -> trace (any hit) -> light_gather on a second stream.  Queues are compacted
+// generation are lit by light_setup -> trace (any hit) -> light_gather.  Queues are compacted
 // with wave ballots and split into 64 shards; frames shard over ranks by 32x32 image tiles (the reference's
 // square_dynamic tile, src/main.cpp:441).  A slot's random numbers depend only on (seed, pixel, sample, path node),
 // so results do not depend on launch geometry, batching, sharding or scheduling.
@@ -1794,8 +1794,12 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         s->lit.push_back(b);
     }
-    static const bool one_stream = getenv("RT_ONE_STREAM") != nullptr;   // diagnostic: kernel times without overlap
-    hipStream_t lighting = one_stream ? s->stream : s->stream2;
+    // The lighting chain of a generation can run on a second stream beside the closest-hit trace and shading of the next
+    // one (RT_TWO_STREAMS=1).  It is off by default: once every kernel fills the chip by itself the overlap gains nothing
+    // (4K / 64 spp frame 743 vs 740 ms, 1080p / 1 spp frame 1.27 vs 1.24 ms), and on one stream the per-kernel event times
+    // are the kernels' own.
+    static const bool two_streams = getenv("RT_TWO_STREAMS") != nullptr && atoi(getenv("RT_TWO_STREAMS")) != 0;
+    hipStream_t lighting = two_streams ? s->stream2 : s->stream;
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -1823,9 +1827,9 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         // consumer grids: a whole number of workgroups per shard
         const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
         const unsigned grid = per_shard * N_SHARDS;
-        // Two streams: `stream` walks the paths (closest hit, shade), `stream2` lights the vertices of a generation
-        // while `stream` already traces the next one, so that the tail of one kernel is filled by the other chain.
-        // Vertex and shadow buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
+        // `stream` walks the paths (closest hit, shade); `lighting` (the same stream unless RT_TWO_STREAMS is set) lights
+        // the vertices of a generation, with two streams while `stream` already traces the next one.  Vertex and shadow
+        // buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
         for (int gen = 0; gen < n_gen; ++gen) {
             launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
             if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));

@@ -1,9 +1,9 @@
-# A/B of environment settings on the GPU box (one stream, per-kernel times of a 4K / 64 spp frame of the 1M-triangle scene):
+# A/B of environment settings on the GPU box (per-kernel times of a 4K / 64 spp frame of the 1M-triangle scene):
 #   tools/ab_env.sh "" "RT_TILE_ORDER=0" ...
 cd $GRAFT_REPO_ROOT
 for e in "$@"; do
   echo "== ${e:-default}"
-  env RT_ONE_STREAM=1 $e timeout -k 10 200 python3 -u -c '
+  env $e timeout -k 10 200 python3 -u -c '
 import sys
 sys.path.insert(0, ".")
 import raytracer_amd as R

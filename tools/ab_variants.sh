@@ -1,12 +1,12 @@
 # A/B of build variants of the GPU library on the GPU box: tools/ab_variants.sh "<flags A>" "<flags B>" ...
 # Each variant is built in the CPU container beforehand as gpurun_out/variants/librt_gpu_<n>.so by tools/build_variants.sh;
-# here each one is copied over raytracer_amd/librt_gpu.so in the box's scratch copy and timed (one stream, per-kernel).
+# here each one is copied over raytracer_amd/librt_gpu.so in the box's scratch copy and timed (per-kernel event times).
 cd $GRAFT_REPO_ROOT
 cp raytracer_amd/librt_gpu.so /tmp/librt_gpu_orig.so
 for v in variants/librt_gpu_*.so; do
   echo "== $v $(cat ${v%.so}.flags)"
   cp $v raytracer_amd/librt_gpu.so
-  RT_ONE_STREAM=1 timeout -k 10 200 python3 -u -c '
+  timeout -k 10 200 python3 -u -c '
 import sys
 sys.path.insert(0, ".")
 import raytracer_amd as R

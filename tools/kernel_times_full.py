@@ -1,5 +1,5 @@
-"""Per-kernel device times of one frame of a bench workload (HIP events around every launch), once with the two
-streams of the render loop and once with everything on one stream (RT_ONE_STREAM=1, kernel times without overlap).
+"""Per-kernel device times of one frame of a bench workload (HIP events around every launch), once on one stream
+(the default) and once with the direct lighting on a second stream (RT_TWO_STREAMS=1).
     python tools/kernel_times_full.py [width height spp]"""
 import os
 import subprocess
@@ -27,6 +27,6 @@ if __name__ == "__main__":
     for one in (False, True):
         env = dict(os.environ)
         if one:
-            env["RT_ONE_STREAM"] = "1"
-        print(("one stream" if one else "two streams") + "".join(f" {k}={v}" for k, v in env.items() if k.startswith("RT_")), flush=True)
+            env["RT_TWO_STREAMS"] = "1"
+        print(("two streams" if one else "one stream") + "".join(f" {k}={v}" for k, v in env.items() if k.startswith("RT_")), flush=True)
         subprocess.run([sys.executable, "-c", CHILD] + args, env=env, check=True)
