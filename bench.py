@@ -249,6 +249,7 @@ def main():
         bytes_per_launch = per_frame[name] / launches_per_frame
         ms_per_launch = total_ms / launches
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+        traffic = pmc_traffic(args.workload, name) if world == 1 else None
         line = {
             "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -265,7 +266,11 @@ def main():
             "rays_per_frame": rays / args.steps, "traversals_per_frame": traced / args.steps,
             "value_traversals": traced / elapsed / 1e6,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, name) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # the algorithmic bytes are served largely by LDS, L1 and L2, so their rate may pass the HBM peak;
+                         # the HBM-side rate is the measured traffic over the same launch time
+                         "traffic_rate": traffic / (ms_per_launch * 1e-3) / 1e9 if traffic else None,
+                         "traffic_frac": traffic / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                          "kernel_ms_per_launch": ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches_per_frame": launches_per_frame,
                          "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()}},
