@@ -1180,8 +1180,12 @@ static unsigned wavefront_capacity(unsigned shadow_mult) {
         long v = atol(e);
         if (v >= 65536 && v <= (1l << 28)) return (unsigned)((unsigned long long)v / unit * unit);
     }
-    const unsigned long long budget = 128000000000ull, per_entry = 348ull + 136ull * shadow_mult;
-    return (unsigned)(std::min<unsigned long long>(budget / per_entry, 1ull << 28) / unit * unit);
+    unsigned long long budget = 128000000000ull;
+    size_t free_bytes = 0, total_bytes = 0;   // share a device that is already in use: at most 3/4 of what is free
+    if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) budget = std::min<unsigned long long>(budget, (unsigned long long)free_bytes / 4 * 3);
+    (void)hipGetLastError();
+    const unsigned long long per_entry = 348ull + 136ull * shadow_mult;
+    return (unsigned)(std::max<unsigned long long>(std::min<unsigned long long>(budget / per_entry, 1ull << 28) / unit, 4) * unit);
 }
 
 // Allocates the wavefront state for `cap` entries; on failure everything allocated so far is released.
