@@ -27,6 +27,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -34,6 +35,7 @@
 
 #include "gpu_render.h"
 #include "oracle_math.h"
+#include "rt_wide.h"   // the product's wide-tree builder: the checker walks the records the product walks
 
 namespace {
 
@@ -131,6 +133,10 @@ struct orc_scene {
     std::vector<rt_bvh_node> nodes;
     std::vector<rt_bvh_prim> prims;
     std::vector<TriAccel> accel;
+    // the product's wide tree (raytracer_amd/csrc/gpu/rt_wide.h), built on demand by orc_intersect_wide
+    std::vector<rt::WideRecord> wide;
+    std::vector<int> leaf_node_at;   // first leaf entry -> the leaf's node
+    int wide_state = 0;   // 0 not built yet, 1 built, -1 the tree does not qualify
 };
 
 namespace {
@@ -141,6 +147,9 @@ struct Hit {
     int shape = -1;      // position in get_shapes() order: triangles, spheres, planes
     int instance = -1;   // index into instances (triangles only)
 };
+
+std::atomic<long> g_walk_mismatches{0};
+int g_walk_wide = 0;   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
 
 struct Tracer {
     const orc_scene &S;
@@ -245,6 +254,21 @@ struct Tracer {
     }
     // bvh::intersect, src/bvh.cpp:383-480
     Hit intersect(V o, V d, float time, bool culling, float eps, bool any_hit, float stop_t) {
+        if (g_walk_wide == 1 && S.wide_state == 1) return intersect_wide(o, d, time, culling, eps, any_hit, stop_t);
+        if (g_walk_wide == 2 && S.wide_state == 1) {   // both walks: report rays on which they disagree
+            g_walk_wide = 0;
+            const Counters keep = cnt;
+            const Hit a = intersect(o, d, time, culling, eps, any_hit, stop_t);
+            cnt = keep;
+            g_walk_wide = 2;
+            const Hit b = intersect_wide(o, d, time, culling, eps, any_hit, stop_t);
+            if (a.hit != b.hit || a.shape != b.shape || a.instance != b.instance || memcmp(&a.t, &b.t, 4) != 0) {
+                if (g_walk_mismatches++ < 8)
+                    fprintf(stderr, "walks disagree: o %.9g %.9g %.9g d %.9g %.9g %.9g any %d stop %.9g eps %g: two-child %d/%d t %.9g, wide %d/%d t %.9g\n",
+                            o.x, o.y, o.z, d.x, d.y, d.z, (int)any_hit, stop_t, eps, a.hit ? a.shape : -1, a.instance, a.t, b.hit ? b.shape : -1, b.instance, b.t);
+            }
+            return a;
+        }
         Hit h;
         h.t = stop_t;
         const int ntri = (int)S.triangles.size(), nsph = (int)S.spheres.size();
@@ -299,6 +323,125 @@ struct Tracer {
             }
         }
         return h;
+    }
+
+    // The walk of the product's wide tree (wide_step in raytracer_amd/csrc/gpu/rt_device.h), one ray at a time on the
+    // host: same record decoding, same arithmetic, same visit order; leaves are tested as in intersect() above.  Used
+    // to check that the wide walk finds what the reference's two-child walk finds.
+    Hit intersect_wide(V o, V d, float time, bool culling, float eps, bool any_hit, float stop_t) {
+        Hit h;
+        h.t = stop_t;
+        const int ntri = (int)S.triangles.size(), nsph = (int)S.spheres.size();
+        for (int pi = 0; pi < (int)S.planes.size(); ++pi) {
+            float tc;
+            if (plane_intersect(pi, o, d, eps, tc)) {
+                if (tc > eps && tc < h.t) {
+                    h.t = tc;
+                    h.hit = true;
+                    h.shape = ntri + nsph + pi;
+                    h.instance = -1;
+                    if (any_hit) return h;
+                }
+            }
+        }
+        if (S.nodes.empty()) return h;
+        V inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
+        ++cnt.nodes;
+        if (!slab(S.nodes[0], o, inv, neg, h.t)) return h;
+        const unsigned sgn = (unsigned)(neg[0] | neg[1] << 1 | neg[2] << 2) * 0x49u;
+        struct Entry {
+            int ref;
+            float t;
+        };
+        Entry stack[64];
+        int top = 0;
+        int cur = 0;
+        const int POP = 0x40000000;
+        const float oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+        for (;;) {
+            if (cur == POP) {
+                bool got = false;
+                while (top > 0) {
+                    --top;
+                    if (any_hit || stack[top].t < h.t) {
+                        cur = stack[top].ref;
+                        got = true;
+                        break;
+                    }
+                }
+                if (!got) return h;
+            }
+            if (cur < 0) {   // leaf reference: 1 << 31 | (n - 1) << 24 | first entry
+                const int n = (((unsigned)cur >> 24) & 0x7f) + 1, first = cur & 0xffffff;
+                // the leaf's own (exact) box decides whether its entries are tested, as in the two-child walk: the
+                // quantised boxes only decide what is looked at
+                ++cnt.nodes;
+                if (!slab(S.nodes[(size_t)S.leaf_node_at[(size_t)first]], o, inv, neg, h.t)) {
+                    cur = POP;
+                    continue;
+                }
+                for (int i = 0; i < n; ++i) {
+                    const rt_bvh_prim &pr = S.prims[first + i];
+                    float tc;
+                    bool ok = pr.shape < ntri ? tri_intersect(pr.shape, pr.instance, o, d, time, culling, eps, tc)
+                                              : sphere_intersect(pr.shape - ntri, o, d, eps, tc);
+                    if (ok && tc > eps && tc < h.t) {
+                        h.t = tc;
+                        h.hit = true;
+                        h.shape = pr.shape;
+                        h.instance = pr.instance;
+                        if (any_hit) return h;
+                    }
+                }
+                cur = POP;
+                continue;
+            }
+            const float *f = S.wide[(size_t)cur].f;
+            unsigned w[16];
+            memcpy(w, f, sizeof w);
+            const unsigned head = w[3];
+            float scale[3];
+            const unsigned sx_bits = head & 0x7f800000u;
+            memcpy(&scale[0], &sx_bits, 4);
+            scale[1] = f[14], scale[2] = f[15];
+            const unsigned along = sgn & head;
+            const bool s_root = (along & 7u) != 0, s_l = (along & 0x38u) != 0, s_r = (along & 0x1c0u) != 0;
+            int slot_at[4];   // visit position -> slot
+            {
+                const int a0 = s_l ? 1 : 0, a1 = s_l ? 0 : 1, b0 = s_r ? 3 : 2, b1 = s_r ? 2 : 3;
+                if (s_root) slot_at[0] = b0, slot_at[1] = b1, slot_at[2] = a0, slot_at[3] = a1;
+                else slot_at[0] = a0, slot_at[1] = a1, slot_at[2] = b0, slot_at[3] = b1;
+            }
+            const unsigned qlo[3] = {w[8], w[10], w[12]}, qhi[3] = {w[9], w[11], w[13]};
+            float te[4], tx[4];
+            bool pass[4];
+            int ref[4];
+            for (int k = 0; k < 4; ++k) {
+                const int sl = slot_at[k];
+                float tmin = 0, tmax = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = fmaf((float)((qlo[a] >> (8 * sl)) & 255u), scale[a], f[a]);
+                    const float hi = fmaf((float)((qhi[a] >> (8 * sl)) & 255u), scale[a], f[a]);
+                    const float t_in = ((neg[a] ? hi : lo) - oo[a]) * ii[a], t_out = ((neg[a] ? lo : hi) - oo[a]) * ii[a];
+                    // fmaxf / fminf: of a number and a NaN the number, as the device's max3 / min3
+                    tmin = a == 0 ? t_in : fmaxf(tmin, t_in);
+                    tmax = a == 0 ? t_out : fminf(tmax, t_out);
+                }
+                ref[k] = (int)w[4 + sl];
+                te[k] = tmin, tx[k] = tmax;
+                pass[k] = tmin <= tmax && tmax > 0.0f && tmin < h.t && ref[k] != rt::WIDE_REF_NONE;
+            }
+            int first = -1;
+            for (int k = 0; k < 4; ++k)
+                if (pass[k]) {
+                    first = k;
+                    break;
+                }
+            for (int k = 3; k > first && first >= 0; --k)
+                if (pass[k] && top < 64) stack[top++] = {ref[k], te[k]};
+            cur = first >= 0 ? ref[first] : POP;
+        }
     }
 
     // ---- camera (camera::get_samples, src/camera.cpp:117-224) ---------------------------------
@@ -1376,6 +1519,46 @@ int orc_intersect(orc_scene *s, const float *o, const float *d, float time, int 
     *instance = h.hit ? h.instance : -1;
     *t = h.t;
     return h.hit ? 1 : 0;
+}
+
+// The same probe through the product's wide tree; returns -1 when the scene's tree does not qualify for one.
+int orc_intersect_wide(orc_scene *s, const float *o, const float *d, float time, int culling, float eps, int any_hit, float stop_t,
+                       int32_t *shape, int32_t *instance, float *t) {
+    if (s->wide_state == 0) {
+        int root = 0, n_top = 0;
+        s->leaf_node_at.assign(s->prims.size(), -1);
+        for (size_t i = 0; i < s->nodes.size(); ++i)
+            if (s->nodes[i].n_prims > 0) s->leaf_node_at[(size_t)s->nodes[i].offset] = (int)i;
+        s->wide_state = rt::build_wide_nodes(s->nodes.data(), (int)s->nodes.size(), 127, 64, s->wide, root, n_top) ? 1 : -1;
+    }
+    if (s->wide_state < 0) return -1;
+    rt_camera_desc cam{};
+    Tracer tr(*s, cam);
+    Hit h = tr.intersect_wide(mk(o), mk(d), time, culling != 0, eps, any_hit != 0, stop_t);
+    *shape = h.hit ? h.shape : -1;
+    *instance = h.hit ? h.instance : -1;
+    *t = h.t;
+    return h.hit ? 1 : 0;
+}
+
+// 1: orc_render / orc_trace_primary walk the wide tree of scenes whose wide tree has been built (orc_intersect_wide
+// builds it); counters then count the root box only.  For checking that both walks give the same image.
+void orc_set_wide(int on) { g_walk_wide = on; }
+long orc_walk_mismatches(void) { return g_walk_mismatches.load(); }
+
+// Many rays at once: o, d are n x 3; mode 0 the two-child walk, 1 the wide walk.  Results per ray: shape (-1 none),
+// instance, distance.
+int orc_intersect_many(orc_scene *s, int mode, int n, const float *o, const float *d, const float *stop_t, int any_hit, float eps,
+                       int32_t *shape, int32_t *instance, float *t) {
+    for (int i = 0; i < n; ++i) {
+        const int keep = g_walk_wide;
+        g_walk_wide = 0;
+        int rc = mode ? orc_intersect_wide(s, o + 3 * i, d + 3 * i, 0.f, 0, eps, any_hit, stop_t[i], shape + i, instance + i, t + i)
+                      : orc_intersect(s, o + 3 * i, d + 3 * i, 0.f, 0, eps, any_hit, stop_t[i], shape + i, instance + i, t + i);
+        g_walk_wide = keep;
+        if (rc < 0) return rc;
+    }
+    return 0;
 }
 
 // Probes of the shared arithmetic definitions, used to check the device code bit for bit.

@@ -28,6 +28,7 @@
 #include "gpu_render.h"
 #include "rt_math.h"
 #include "rt_device.h"
+#include "rt_wide.h"
 
 using namespace rt;
 
@@ -248,14 +249,20 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
     }
 }
 
-template <bool ANY, bool COUNT>
+// WIDE: interior nodes are taken from the wide tree (four quantised boxes per 64-byte record, see wide_step) instead
+// of the two-box records.  The counting variants always walk the two-box records, whose visits are the reference's.
+template <bool ANY, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
+    static_assert(!(WIDE && COUNT), "the counters follow the two-box walk");
     __shared__ uint2 stack_lds[LDS_STACK * 256];
     __shared__ float4 top_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 1];
     uint2 *lds = stack_lds + threadIdx.x;
     uint2 spill[SPILL_STACK];
-    const int n_top = TOP_NODES > 0 ? min(S.n_top, TOP_NODES) : 0;
-    for (int i = threadIdx.x; i < 4 * n_top; i += 256) top_nodes[i] = S.nodes[i];
+    const int n_top = TOP_NODES > 0 ? min(WIDE ? S.n_wtop : S.n_top, TOP_NODES) : 0;
+    {
+        const float4 *records = WIDE ? S.wnodes : S.nodes;
+        for (int i = threadIdx.x; i < 4 * n_top; i += 256) top_nodes[i] = records[i];
+    }
     __syncthreads();
     const int shard = blockIdx.x % N_SHARDS;
     unsigned *ctr = counter_of(W, ANY ? Q_SHADOW : Q_PATH, gen, shard);
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
     unsigned idx = 0;
     float dist = 0.f;   // any hit: distance to the light sample
     bool exhausted = count == 0;
+    bool fresh = false;   // WIDE: the leaf at r.cur has just been reached, its own box is still to be tested
 
     for (;;) {
         const unsigned long long idle = __ballot(r.cur == REF_IDLE);
@@ -316,6 +324,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                                 go = ray_begin<false, COUNT>(S, r, eps, 1e30f, c);
                             }
                         }
+                        if (WIDE && go) r.cur = S.wroot_ref;
                         if (!go) {
                             ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                             r.cur = REF_IDLE;
@@ -331,27 +340,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                 r.cur = REF_IDLE;
             }
+            fresh = true;
         }
         const unsigned long long at_node = __ballot((unsigned)r.cur < (unsigned)REF_POP);
         const unsigned long long at_leaf = __ballot(r.cur < 0);
         const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
         if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) {
-            if ((unsigned)r.cur < (unsigned)REF_POP) node_step<COUNT>(S, r, lds, spill, top_nodes, n_top, c);
+            if ((unsigned)r.cur < (unsigned)REF_POP) {
+                if (WIDE) {
+                    wide_step(S, r, lds, spill, top_nodes, n_top);
+                    fresh = true;
+                } else
+                    node_step<COUNT>(S, r, lds, spill, top_nodes, n_top, c);
+            }
         } else if (n_leaf) {
             if (r.cur < 0) {
                 const int k = r.cur & 0xffffff;
-                float tc;
-                bool done = false;
-                if (prim_test<COUNT>(S, k, r, eps, tc, c) && tc > eps && tc < r.t) {
-                    r.t = tc;
-                    r.prim = k;
-                    done = ANY;
+                bool inside = true;
+                if (WIDE && fresh) {
+                    // The quantised boxes decide what the walk looks at; whether a leaf's entries are tested is decided by
+                    // the leaf's own box, as in the two-box walk.  (A ray that passes the leaf's box passes the boxes of
+                    // all its ancestors, which contain it, so this one test stands for the whole chain.)
+                    fresh = false;
+                    const float4 b0 = S.leaf_boxes[2 * (size_t)k], b1 = S.leaf_boxes[2 * (size_t)k + 1];
+                    float tm;
+                    inside = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0, r.iy < 0, r.iz < 0, tm) && tm < r.t;
+                    if (!inside) r.cur = REF_POP;
                 }
-                if (done) {
-                    ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
-                    r.cur = REF_IDLE;
-                } else {
-                    r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
+                if (inside) {
+                    float tc;
+                    bool done = false;
+                    if (prim_test<COUNT>(S, k, r, eps, tc, c) && tc > eps && tc < r.t) {
+                        r.t = tc;
+                        r.prim = k;
+                        done = ANY;
+                    }
+                    if (done) {
+                        ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
+                        r.cur = REF_IDLE;
+                    } else {
+                        r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
+                    }
                 }
             }
         }
@@ -1115,7 +1144,7 @@ struct rt_scene {
     int slot_table = -1;              // offset of the deferred-mode slot table in light_of
     std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
-    unsigned trace_blocks[2][2] = {{0, 0}, {0, 0}};   // resident workgroups of trace_kernel<ANY, COUNT>, a multiple of N_SHARDS
+    unsigned trace_blocks[2][3] = {{0, 0, 0}, {0, 0, 0}};   // resident workgroups of trace_kernel<ANY, ...> (plain, counting, wide), a multiple of N_SHARDS
     // per-kernel timing (rt_set_profiling): every launch bracketed by two events on `stream`
     bool profiling = false;
     std::vector<hipEvent_t> event_pool;
@@ -1299,12 +1328,17 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned sha
 // (the grid a one-ray-per-lane launch would use; small batches need fewer workgroups than the chip holds).
 static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned grid_limit, int gen, int whitted) {
     const bool count = s->counters;
-    unsigned &blocks = s->trace_blocks[any][count];
+    // the wide tree serves every render without counters; RT_WIDE_NODES=0 keeps the two-box records (A/B timing)
+    static const bool wide_env = !(getenv("RT_WIDE_NODES") && atoi(getenv("RT_WIDE_NODES")) == 0);
+    const bool wide = !count && wide_env && s->dev.wnodes != nullptr;
+    typedef void (*TraceFn)(DevScene, Wavefront, int, int, TraceTuning, unsigned long long *);
+    const TraceFn fn = wide    ? (any ? trace_kernel<true, false, true> : trace_kernel<false, false, true>)
+                       : count ? (any ? trace_kernel<true, true, false> : trace_kernel<false, true, false>)
+                               : (any ? trace_kernel<true, false, false> : trace_kernel<false, false, false>);
+    unsigned &blocks = s->trace_blocks[any][wide ? 2 : (count ? 1 : 0)];
     if (!blocks) {
         int per_cu = 0, cus = 0;
-        const void *fn = any ? (count ? (const void *)trace_kernel<true, true> : (const void *)trace_kernel<true, false>)
-                             : (count ? (const void *)trace_kernel<false, true> : (const void *)trace_kernel<false, false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess || cus < 1) cus = 256;
         (void)hipGetLastError();
         blocks = std::max(1u, (unsigned)per_cu * (unsigned)cus / N_SHARDS) * N_SHARDS;
@@ -1317,17 +1351,7 @@ static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned gri
         if (const char *e = getenv("RT_TRACE_LEAF_MIN")) t.leaf_min = std::min(64, std::max(1, atoi(e)));
         return t;
     }();
-    if (any) {
-        if (count)
-            hipLaunchKernelGGL((trace_kernel<true, true>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
-        else
-            hipLaunchKernelGGL((trace_kernel<true, false>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
-    } else {
-        if (count)
-            hipLaunchKernelGGL((trace_kernel<false, true>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
-        else
-            hipLaunchKernelGGL((trace_kernel<false, false>), grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
-    }
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
 }
 
 extern "C" {
@@ -1486,6 +1510,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             return 3;
         }
     }
+    std::vector<WideRecord> wnodes;   // 64 bytes each, read as 4 x float4 on the device
+    int wroot_ref = 0, n_wtop = 0;
+    const bool has_wide = build_wide_nodes(d->bvh_nodes, d->n_bvh_nodes, TOP_NODES, LDS_STACK + SPILL_STACK, wnodes, wroot_ref, n_wtop);
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
     auto as_float = [](int v) {
@@ -1551,6 +1578,21 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         keep(tmp_);                                                                   \
     } while (0)
     UP(nodes, nodes.data(), nodes.size());
+    std::vector<float4> leaf_boxes;   // per first leaf entry: the leaf's own box {min.xyz, max.x} {max.yz, 0, 0}
+    if (has_wide) {
+        leaf_boxes.assign((size_t)d->n_bvh_prims * 2, make_float4(0, 0, 0, 0));
+        for (int i = 0; i < d->n_bvh_nodes; ++i) {
+            const rt_bvh_node &n = d->bvh_nodes[i];
+            if (n.n_prims == 0) continue;
+            leaf_boxes[2 * (size_t)n.offset] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);
+            leaf_boxes[2 * (size_t)n.offset + 1] = make_float4(n.bmax[1], n.bmax[2], 0.f, 0.f);
+        }
+        UP(leaf_boxes, leaf_boxes.data(), leaf_boxes.size());
+        static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
+        UP(wnodes, (const float4 *)wnodes.data(), wnodes.size() * 4);
+        D.wroot_ref = wroot_ref;
+        D.n_wtop = n_wtop;
+    }
     UP(prims, prims.data(), prims.size());
     UP(inst, inst.data(), inst.size());
     UP(instances, d->instances, d->n_instances);

@@ -27,8 +27,16 @@ enum {
 //         sphere   {...unused...}                 {0, bits(-1 - sphere), bits(shape), bits(123456)}
 // inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
 //         flags bit0 = identity transform, bit1 = has motion blur
+// wnodes: 4 x float4 per WIDE node: an interior node merged with those of its two children that are interior, so
+//         that it holds the boxes of up to four descendants ("slots": 0, 1 from the left child, 2, 3 from the right),
+//         each box quantised to 8 bits per coordinate on a grid local to the node (never smaller than the box):
+//         {origin.xyz, bits(2^ex | axis masks)} {bits(slot refs 0..3)} {lo.x, hi.x, lo.y, hi.y: one byte per slot}
+//         {lo.z, hi.z, bits(2^ey), bits(2^ez)};  axis masks: 1 << split axis of the node | of its left child << 3 | of
+//         its right child << 6;  slot ref: wide node index, leaf reference as above, or WREF_NONE
 struct DevScene {
     const float4 *nodes;
+    const float4 *wnodes;   // null when the scene has no wide tree
+    const float4 *leaf_boxes;   // with a wide tree, per first leaf entry k: the leaf's own box {min.xyz, max.x} {max.yz, -, -} at [2k]
     const float4 *prims;
     const float4 *inst;
     const rt_instance *instances;
@@ -46,6 +54,7 @@ struct DevScene {
     int n_triangles, n_spheres, n_planes, n_lights, n_nodes;
     int root_ref;
     int n_top;   // the first n_top node records are the top of the tree in breadth-first order (kept in LDS by the trace kernel)
+    int wroot_ref, n_wtop;   // the same for the wide tree
     float root_min[3], root_max[3];
     float ieps, seps, max_depth;
     float ambient[3], bg[3];
@@ -133,7 +142,7 @@ struct RayState {
     float t;            // closest accepted distance so far (starts at the ray's stop distance)
     int prim;           // its leaf entry; <= -2 plane (-2 - index); -1 none
     int cur, sp;
-    int sgn;            // bit a set: direction component a is negative
+    int sgn;            // bit a (and a + 3, a + 6) set: direction component a is negative
     bool culling;
 };
 
@@ -163,7 +172,7 @@ __device__ __forceinline__ bool ray_begin(const DevScene &S, RayState &r, float 
     r.ix = rt_div(1.0f, r.dx);
     r.iy = rt_div(1.0f, r.dy);
     r.iz = rt_div(1.0f, r.dz);
-    r.sgn = (r.ix < 0 ? 1 : 0) | (r.iy < 0 ? 2 : 0) | (r.iz < 0 ? 4 : 0);
+    r.sgn = ((r.ix < 0 ? 1 : 0) | (r.iy < 0 ? 2 : 0) | (r.iz < 0 ? 4 : 0)) * 0x49;   // three copies: bits 0-2, 3-5, 6-8 (see wide_step)
     if (COUNT) ++c.nodes;
     float tm;
     if (!slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0,
@@ -229,6 +238,70 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
         if (pn & pf) stack_push(r, lds, spill, make_uint2((unsigned)far_ref, __float_as_uint(neg ? tl : tr)));
     }
     r.cur = pn ? near_ref : (pf ? far_ref : REF_POP);
+}
+
+// One wide node (see DevScene::wnodes): up to four boxes at once, two levels of the tree per fetch of the same 64
+// bytes.  The slots are visited in the order the two-level walk would visit them -- the side of the node's split the
+// ray looks along first, and inside each side the same rule with that child's split axis -- so leaves are reached in
+// the same relative order.  The quantised boxes contain the exact ones, and the arithmetic below is monotonic in the
+// box coordinates, so whatever passes the exact test passes this one: the walk reaches a superset of the leaves the
+// two-level walk visits; the trace kernel then tests each leaf's own exact box before its entries, which removes the
+// surplus (see there), so both walks test the same entries in the same order and keep the same hit.  A stack
+// entry's distance is the (never later) entry into the quantised box.
+constexpr int WREF_NONE = 0x40000002;   // = WIDE_REF_NONE of rt_wide.h
+__device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+__device__ __forceinline__ f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, f2{b, b}, f2{c, c}); }
+
+__device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, const float4 *top, int n_top) {
+    float4 n0, n1, n2, n3;
+    if (TOP_NODES > 0 && r.cur < n_top) {
+        const float4 *np = top + 4 * r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    } else {
+        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    }
+    const unsigned head = __float_as_uint(n0.w);
+    const float sx = __uint_as_float(head & 0x7f800000u), sy = n3.z, sz = n3.w;
+    const unsigned along = (unsigned)r.sgn & head;
+    const bool s_root = (along & 7u) != 0, s_l = (along & 0x38u) != 0, s_r = (along & 0x1c0u) != 0;
+    // visit position -> slot, one byte each
+    const unsigned lo16 = s_l ? 0x0001u : 0x0100u, hi16 = s_r ? 0x0203u : 0x0302u;
+    const unsigned sel = s_root ? (lo16 << 16 | hi16) : (hi16 << 16 | lo16);
+    const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
+    const unsigned qlx = __float_as_uint(n2.x), qhx = __float_as_uint(n2.y), qly = __float_as_uint(n2.z), qhy = __float_as_uint(n2.w);
+    const unsigned qlz = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);
+    const unsigned ex = __builtin_amdgcn_perm(0, nx ? qhx : qlx, sel), fx = __builtin_amdgcn_perm(0, nx ? qlx : qhx, sel);
+    const unsigned ey = __builtin_amdgcn_perm(0, ny ? qhy : qly, sel), fy = __builtin_amdgcn_perm(0, ny ? qly : qhy, sel);
+    const unsigned ez = __builtin_amdgcn_perm(0, nz ? qhz : qlz, sel), fz = __builtin_amdgcn_perm(0, nz ? qlz : qhz, sel);
+    // entry and exit distances of positions (0, 1) and (2, 3), per axis: ((origin + q * 2^e) - o) * (1 / d)
+#define RT_WIDE_AXIS(q, s, p, o, inv, A, B)                                   \
+    const f2 A = (fma2(f2{ubyte_f(q, 0), ubyte_f(q, 1)}, s, p) - o) * inv;   \
+    const f2 B = (fma2(f2{ubyte_f(q, 2), ubyte_f(q, 3)}, s, p) - o) * inv;
+    RT_WIDE_AXIS(ex, sx, n0.x, r.ox, r.ix, ex01, ex23)
+    RT_WIDE_AXIS(fx, sx, n0.x, r.ox, r.ix, fx01, fx23)
+    RT_WIDE_AXIS(ey, sy, n0.y, r.oy, r.iy, ey01, ey23)
+    RT_WIDE_AXIS(fy, sy, n0.y, r.oy, r.iy, fy01, fy23)
+    RT_WIDE_AXIS(ez, sz, n0.z, r.oz, r.iz, ez01, ez23)
+    RT_WIDE_AXIS(fz, sz, n0.z, r.oz, r.iz, fz01, fz23)
+#undef RT_WIDE_AXIS
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(ex01.x, ey01.x), ez01.x), m0 = __builtin_fminf(__builtin_fminf(fx01.x, fy01.x), fz01.x);
+    const float t1 = __builtin_fmaxf(__builtin_fmaxf(ex01.y, ey01.y), ez01.y), m1 = __builtin_fminf(__builtin_fminf(fx01.y, fy01.y), fz01.y);
+    const float t2 = __builtin_fmaxf(__builtin_fmaxf(ex23.x, ey23.x), ez23.x), m2 = __builtin_fminf(__builtin_fminf(fx23.x, fy23.x), fz23.x);
+    const float t3 = __builtin_fmaxf(__builtin_fmaxf(ex23.y, ey23.y), ez23.y), m3 = __builtin_fminf(__builtin_fminf(fx23.y, fy23.y), fz23.y);
+    // slot refs in visit order
+    const int c0 = __float_as_int(n1.x), c1 = __float_as_int(n1.y), c2 = __float_as_int(n1.z), c3 = __float_as_int(n1.w);
+    const int e0 = s_l ? c1 : c0, e1 = s_l ? c0 : c1, e2 = s_r ? c3 : c2, e3 = s_r ? c2 : c3;
+    const int d0 = s_root ? e2 : e0, d1 = s_root ? e3 : e1, d2 = s_root ? e0 : e2, d3 = s_root ? e1 : e3;
+    const bool h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < r.t) & (d0 != WREF_NONE);
+    const bool h1 = (t1 <= m1) & (m1 > 0.0f) & (t1 < r.t) & (d1 != WREF_NONE);
+    const bool h2 = (t2 <= m2) & (m2 > 0.0f) & (t2 < r.t) & (d2 != WREF_NONE);
+    const bool h3 = (t3 <= m3) & (m3 > 0.0f) & (t3 < r.t) & (d3 != WREF_NONE);
+    // the first position that passes is next; the others wait on the stack, the earliest on top
+    if (h3 & (h0 | h1 | h2)) stack_push(r, lds, spill, make_uint2((unsigned)d3, __float_as_uint(t3)));
+    if (h2 & (h0 | h1)) stack_push(r, lds, spill, make_uint2((unsigned)d2, __float_as_uint(t2)));
+    if (h1 & h0) stack_push(r, lds, spill, make_uint2((unsigned)d1, __float_as_uint(t1)));
+    r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 
 // Pops until an entry whose box still starts before the closest hit; false when the stack is empty.  With

@@ -1,0 +1,157 @@
+// Host-side construction of the wide tree the trace kernel walks (DevScene::wnodes in rt_device.h describes the
+// record).  Plain C++: rt_scene_create uses it, and the CPU checker builds the same records to walk them on the host.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "gpu_render.h"
+
+namespace rt {
+
+struct WideRecord {
+    float f[16];
+};
+constexpr int WIDE_REF_NONE = 0x40000002;   // slot without a box
+
+// Builds the wide tree (DevScene::wnodes) from the two-child tree: node i, its interior children and their children
+// become one record.  Returns false (and the scene renders from the two-box records) when the tree does not qualify:
+// a single leaf, a box that is not finite, or a walk that could need more than the 64 stack entries.
+inline bool build_wide_nodes(const rt_bvh_node *N, int n_nodes, int top_nodes, int stack_entries, std::vector<WideRecord> &out, int &root_ref, int &n_top) {
+    if (n_nodes < 3 || N[0].n_prims != 0) return false;
+    auto slots_of = [&](int i, int slot[4], int axis_of[3]) {
+        const int L = i + 1, R = N[i].offset;
+        axis_of[0] = N[i].axis, axis_of[1] = axis_of[2] = -1;
+        if (N[L].n_prims == 0) slot[0] = L + 1, slot[1] = N[L].offset, axis_of[1] = N[L].axis; else slot[0] = L, slot[1] = -1;
+        if (N[R].n_prims == 0) slot[2] = R + 1, slot[3] = N[R].offset, axis_of[2] = N[R].axis; else slot[2] = R, slot[3] = -1;
+    };
+    // record order: the first TOP_NODES breadth-first, every subtree below depth-first
+    std::vector<int> index(n_nodes, -1), heads;
+    {
+        std::vector<int> walk{0}, below, stack;
+        for (size_t at = 0; at < walk.size(); ++at) {
+            const int i = walk[at];
+            if ((int)heads.size() >= top_nodes) {
+                below.push_back(i);
+                continue;
+            }
+            index[i] = (int)heads.size();
+            heads.push_back(i);
+            int slot[4], ax[3];
+            slots_of(i, slot, ax);
+            for (int k = 0; k < 4; ++k)
+                if (slot[k] >= 0 && N[slot[k]].n_prims == 0) walk.push_back(slot[k]);
+        }
+        n_top = (int)heads.size();
+        for (int root : below) {
+            stack.push_back(root);
+            while (!stack.empty()) {
+                const int i = stack.back();
+                stack.pop_back();
+                index[i] = (int)heads.size();
+                heads.push_back(i);
+                int slot[4], ax[3];
+                slots_of(i, slot, ax);
+                for (int k = 3; k >= 0; --k)
+                    if (slot[k] >= 0 && N[slot[k]].n_prims == 0) stack.push_back(slot[k]);
+            }
+        }
+    }
+    // stack entries a walk can hold below each head: its waiting slots plus the deepest child's need (children first:
+    // `heads` lists every node after its parent)
+    {
+        std::vector<int> need(heads.size(), 0);
+        for (size_t h = heads.size(); h-- > 0;) {
+            int slot[4], ax[3], present = 0, deepest = 0;
+            slots_of(heads[h], slot, ax);
+            for (int k = 0; k < 4; ++k) {
+                if (slot[k] < 0) continue;
+                ++present;
+                if (N[slot[k]].n_prims == 0) deepest = std::max(deepest, need[(size_t)index[slot[k]]]);
+            }
+            need[h] = present - 1 + deepest;
+        }
+        if (need[0] > stack_entries) return false;
+    }
+    auto as_float = [](unsigned v) {
+        float f;
+        memcpy(&f, &v, 4);
+        return f;
+    };
+    out.assign(heads.size(), WideRecord{});
+    for (size_t h = 0; h < heads.size(); ++h) {
+        int slot[4], ax[3];
+        slots_of(heads[h], slot, ax);
+        unsigned ref[4], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+        float origin[3], scale[3];
+        for (int k = 0; k < 4; ++k) {
+            if (slot[k] < 0) {
+                ref[k] = (unsigned)WIDE_REF_NONE;
+                continue;
+            }
+            const rt_bvh_node &c = N[slot[k]];
+            if (c.n_prims == 0) {
+                ref[k] = (unsigned)index[slot[k]];
+            } else {
+                if (c.n_prims > 128 || c.offset >= (1 << 24)) return false;
+                ref[k] = 0x80000000u | ((unsigned)(c.n_prims - 1) << 24) | (unsigned)c.offset;
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int k = 0; k < 4; ++k) {
+                if (slot[k] < 0) continue;
+                const rt_bvh_node &c = N[slot[k]];
+                if (!std::isfinite(c.bmin[a]) || !std::isfinite(c.bmax[a]) || c.bmin[a] > c.bmax[a]) return false;
+                lo = std::min(lo, c.bmin[a]);
+                hi = std::max(hi, c.bmax[a]);
+            }
+            origin[a] = lo;
+            int e = -100;
+            const double extent = (double)hi - (double)lo;
+            if (extent > 0) {
+                int ex;
+                (void)frexp(extent / 255.0, &ex);   // 2^ex > extent / 255
+                e = std::max(ex, -100);
+            }
+            for (;; ++e) {   // grid step 2^e: the smallest with which every box fits 0..255
+                if (e > 126) return false;
+                const float step = ldexpf(1.0f, e);
+                unsigned lo_bytes = 0, hi_bytes = 0;
+                bool fits = true;
+                for (int k = 0; k < 4 && fits; ++k) {
+                    if (slot[k] < 0) {   // an empty slot keeps the inverted box 255..0 (and its ref says so)
+                        lo_bytes |= 255u << (8 * k);
+                        continue;
+                    }
+                    const rt_bvh_node &c = N[slot[k]];
+                    // the decoded coordinate is fmaf(q, step, origin), on the device too: never inside the exact box
+                    int ql = (int)std::min(255.0, std::max(0.0, floor(((double)c.bmin[a] - (double)lo) / (double)step)));
+                    while (ql > 0 && fmaf((float)ql, step, lo) > c.bmin[a]) --ql;
+                    int qh = (int)std::min(256.0, std::max(0.0, ceil(((double)c.bmax[a] - (double)lo) / (double)step)));
+                    while (qh <= 255 && fmaf((float)qh, step, lo) < c.bmax[a]) ++qh;
+                    if (qh > 255) fits = false;
+                    lo_bytes |= (unsigned)ql << (8 * k);
+                    hi_bytes |= (unsigned)(qh & 255) << (8 * k);
+                }
+                if (fits) {
+                    qlo[a] = lo_bytes, qhi[a] = hi_bytes;
+                    scale[a] = step;
+                    break;
+                }
+            }
+        }
+        unsigned head;
+        memcpy(&head, &scale[0], 4);
+        head |= (1u << ax[0]) | (ax[1] >= 0 ? 1u << (3 + ax[1]) : 0u) | (ax[2] >= 0 ? 1u << (6 + ax[2]) : 0u);
+        const float rec[16] = {origin[0], origin[1], origin[2], as_float(head), as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]),
+                               as_float(qlo[0]), as_float(qhi[0]), as_float(qlo[1]), as_float(qhi[1]), as_float(qlo[2]), as_float(qhi[2]), scale[1], scale[2]};
+        memcpy(out[h].f, rec, sizeof rec);
+    }
+    root_ref = 0;
+    return true;
+}
+
+
+}  // namespace rt
