@@ -149,6 +149,7 @@ struct Hit {
 };
 
 std::atomic<long> g_walk_mismatches{0};
+std::atomic<long> g_wide_steps{0}, g_wide_leaf_arrivals{0}, g_wide_leaf_visits{0}, g_two_interior{0}, g_wide_pushes{0}, g_wide_maxsp{0};
 int g_walk_wide = 0;   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
 
 struct Tracer {
@@ -310,6 +311,7 @@ struct Tracer {
                     }
                 }
             } else {
+                ++g_two_interior;
                 int near_i, far_i;
                 if (neg[n.axis]) {
                     near_i = n.offset;
@@ -377,6 +379,7 @@ struct Tracer {
                 // the leaf's own (exact) box decides whether its entries are tested, as in the two-child walk: the
                 // quantised boxes only decide what is looked at
                 ++cnt.nodes;
+                ++g_wide_leaf_arrivals;
                 if (!slab(S.nodes[(size_t)S.leaf_node_at[(size_t)first]], o, inv, neg, h.t)) {
                     cur = POP;
                     continue;
@@ -397,6 +400,7 @@ struct Tracer {
                 cur = POP;
                 continue;
             }
+            ++g_wide_steps;
             const float *f = S.wide[(size_t)cur].f;
             unsigned w[16];
             memcpy(w, f, sizeof w);
@@ -430,7 +434,7 @@ struct Tracer {
                 }
                 ref[k] = (int)w[4 + sl];
                 te[k] = tmin, tx[k] = tmax;
-                pass[k] = tmin <= tmax && tmax > 0.0f && tmin < h.t && ref[k] != rt::WIDE_REF_NONE;
+                pass[k] = tmin <= tmax && tmax > 0.0f && tmin < h.t;   // an empty slot: inverted box; its ref is POP
             }
             int first = -1;
             for (int k = 0; k < 4; ++k)
@@ -439,7 +443,7 @@ struct Tracer {
                     break;
                 }
             for (int k = 3; k > first && first >= 0; --k)
-                if (pass[k] && top < 64) stack[top++] = {ref[k], te[k]};
+                if (pass[k] && top < 64) { stack[top++] = {ref[k], te[k]}; ++g_wide_pushes; if (top > g_wide_maxsp) g_wide_maxsp = top; }
             cur = first >= 0 ? ref[first] : POP;
         }
     }
@@ -1545,6 +1549,10 @@ int orc_intersect_wide(orc_scene *s, const float *o, const float *d, float time,
 // builds it); counters then count the root box only.  For checking that both walks give the same image.
 void orc_set_wide(int on) { g_walk_wide = on; }
 long orc_walk_mismatches(void) { return g_walk_mismatches.load(); }
+// work of the walks since the last call: wide steps, leaves reached by the wide walk, pushes, deepest stack, interior nodes expanded by the two-child walk
+void orc_walk_work(long *out) {
+    out[0] = g_wide_steps.exchange(0), out[1] = g_wide_leaf_arrivals.exchange(0), out[2] = g_wide_pushes.exchange(0), out[3] = g_wide_maxsp.exchange(0), out[4] = g_two_interior.exchange(0);
+}
 
 // Many rays at once: o, d are n x 3; mode 0 the two-child walk, 1 the wide walk.  Results per ray: shape (-1 none),
 // instance, distance.

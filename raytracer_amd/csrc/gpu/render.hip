@@ -285,6 +285,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
     float dist = 0.f;   // any hit: distance to the light sample
     bool exhausted = count == 0;
     bool fresh = false;   // WIDE: the leaf at r.cur has just been reached, its own box is still to be tested
+#ifdef RT_TRACE_PROFILE
+    // diagnostic build: per wave, iterations and participating lanes of each kind of step (closest-hit kernel only),
+    // reported through the work-counter words that are otherwise zero without counters
+    unsigned pf_node_it = 0, pf_node_ln = 0, pf_leaf_it = 0, pf_leaf_ln = 0, pf_pop_it = 0, pf_pop_ln = 0, pf_it = 0, pf_busy = 0;
+#endif
 
     for (;;) {
         const unsigned long long idle = __ballot(r.cur == REF_IDLE);
@@ -335,6 +340,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 break;
             }
         }
+#ifdef RT_TRACE_PROFILE
+        ++pf_it;
+        pf_busy += __popcll(__ballot(r.cur != REF_IDLE));
+        if (const unsigned long long m = __ballot(r.cur == REF_POP)) ++pf_pop_it, pf_pop_ln += __popcll(m);
+#endif
         if (r.cur == REF_POP) {
             if (!stack_pop<(!ANY || COUNT), COUNT>(r, lds, spill, c)) {
                 ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
@@ -345,6 +355,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         const unsigned long long at_node = __ballot((unsigned)r.cur < (unsigned)REF_POP);
         const unsigned long long at_leaf = __ballot(r.cur < 0);
         const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
+#ifdef RT_TRACE_PROFILE
+        if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) ++pf_node_it, pf_node_ln += n_node;
+        else if (n_leaf) ++pf_leaf_it, pf_leaf_ln += n_leaf;
+#endif
         if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) {
             if ((unsigned)r.cur < (unsigned)REF_POP) {
                 if (WIDE) {
@@ -385,6 +399,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
             }
         }
     }
+#ifdef RT_TRACE_PROFILE
+    if (!ANY && lane == 0) {
+        unsigned long long *row = stats + (blockIdx.x % STAT_ROWS) * STAT_WORDS;
+        const unsigned vals[8] = {pf_node_it, pf_node_ln, pf_leaf_it, pf_leaf_ln, pf_pop_it, pf_pop_ln, pf_it, pf_busy};
+        for (int k = 0; k < 4; ++k) atomicAdd(row + 3 + k, (unsigned long long)vals[k]);
+        for (int k = 0; k < 4; ++k) atomicAdd(row + 10 + k, (unsigned long long)vals[4 + k]);
+    }
+#endif
     if (COUNT) {
         flush_counters(c, stats, true);
         if (ANY) {   // the same work again under the any-hit words

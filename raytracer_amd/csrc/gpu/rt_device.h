@@ -32,7 +32,7 @@ enum {
 //         each box quantised to 8 bits per coordinate on a grid local to the node (never smaller than the box):
 //         {origin.xyz, bits(2^ex | axis masks)} {bits(slot refs 0..3)} {lo.x, hi.x, lo.y, hi.y: one byte per slot}
 //         {lo.z, hi.z, bits(2^ey), bits(2^ez)};  axis masks: 1 << split axis of the node | of its left child << 3 | of
-//         its right child << 6;  slot ref: wide node index, leaf reference as above, or WREF_NONE
+//         its right child << 6;  slot ref: wide node index, leaf reference as above, or REF_POP for an empty slot
 struct DevScene {
     const float4 *nodes;
     const float4 *wnodes;   // null when the scene has no wide tree
@@ -217,6 +217,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
     if (TOP_NODES > 0 && r.cur < n_top) {
         const float4 *np = top + 4 * r.cur;
         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        asm volatile("" ::: );   // keeps these LDS reads apart from the global loads below (merged, they become flat loads)
     } else {
         const float4 *np = S.nodes + 4 * (size_t)r.cur;
         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -248,7 +249,6 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
 // two-level walk visits; the trace kernel then tests each leaf's own exact box before its entries, which removes the
 // surplus (see there), so both walks test the same entries in the same order and keep the same hit.  A stack
 // entry's distance is the (never later) entry into the quantised box.
-constexpr int WREF_NONE = 0x40000002;   // = WIDE_REF_NONE of rt_wide.h
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 __device__ __forceinline__ f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, f2{b, b}, f2{c, c}); }
 
@@ -257,6 +257,7 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
     if (TOP_NODES > 0 && r.cur < n_top) {
         const float4 *np = top + 4 * r.cur;
         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        asm volatile("" ::: );   // keeps these LDS reads apart from the global loads below (merged, they become flat loads)
     } else {
         const float4 *np = S.wnodes + 4 * (size_t)r.cur;
         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -289,18 +290,31 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
     const float t1 = __builtin_fmaxf(__builtin_fmaxf(ex01.y, ey01.y), ez01.y), m1 = __builtin_fminf(__builtin_fminf(fx01.y, fy01.y), fz01.y);
     const float t2 = __builtin_fmaxf(__builtin_fmaxf(ex23.x, ey23.x), ez23.x), m2 = __builtin_fminf(__builtin_fminf(fx23.x, fy23.x), fz23.x);
     const float t3 = __builtin_fmaxf(__builtin_fmaxf(ex23.y, ey23.y), ez23.y), m3 = __builtin_fminf(__builtin_fminf(fx23.y, fy23.y), fz23.y);
-    // slot refs in visit order
+    // slot refs in visit order; an empty slot has an inverted box, and should arithmetic that is not a number let it
+    // through, its ref is REF_POP, which only makes the lane pop
     const int c0 = __float_as_int(n1.x), c1 = __float_as_int(n1.y), c2 = __float_as_int(n1.z), c3 = __float_as_int(n1.w);
     const int e0 = s_l ? c1 : c0, e1 = s_l ? c0 : c1, e2 = s_r ? c3 : c2, e3 = s_r ? c2 : c3;
     const int d0 = s_root ? e2 : e0, d1 = s_root ? e3 : e1, d2 = s_root ? e0 : e2, d3 = s_root ? e1 : e3;
-    const bool h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < r.t) & (d0 != WREF_NONE);
-    const bool h1 = (t1 <= m1) & (m1 > 0.0f) & (t1 < r.t) & (d1 != WREF_NONE);
-    const bool h2 = (t2 <= m2) & (m2 > 0.0f) & (t2 < r.t) & (d2 != WREF_NONE);
-    const bool h3 = (t3 <= m3) & (m3 > 0.0f) & (t3 < r.t) & (d3 != WREF_NONE);
+    const bool h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < r.t);
+    const bool h1 = (t1 <= m1) & (m1 > 0.0f) & (t1 < r.t);
+    const bool h2 = (t2 <= m2) & (m2 > 0.0f) & (t2 < r.t);
+    const bool h3 = (t3 <= m3) & (m3 > 0.0f) & (t3 < r.t);
     // the first position that passes is next; the others wait on the stack, the earliest on top
-    if (h3 & (h0 | h1 | h2)) stack_push(r, lds, spill, make_uint2((unsigned)d3, __float_as_uint(t3)));
-    if (h2 & (h0 | h1)) stack_push(r, lds, spill, make_uint2((unsigned)d2, __float_as_uint(t2)));
-    if (h1 & h0) stack_push(r, lds, spill, make_uint2((unsigned)d1, __float_as_uint(t1)));
+    const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
+    if (r.sp + 3 <= LDS_STACK) {   // all in LDS: store without branching, an entry above the top is never read
+        int sp = r.sp;
+        lds[sp * STACK_STRIDE] = make_uint2((unsigned)d3, __float_as_uint(t3));
+        sp += p3 ? 1 : 0;
+        lds[sp * STACK_STRIDE] = make_uint2((unsigned)d2, __float_as_uint(t2));
+        sp += p2 ? 1 : 0;
+        lds[sp * STACK_STRIDE] = make_uint2((unsigned)d1, __float_as_uint(t1));
+        sp += p1 ? 1 : 0;
+        r.sp = sp;
+    } else {
+        if (p3) stack_push(r, lds, spill, make_uint2((unsigned)d3, __float_as_uint(t3)));
+        if (p2) stack_push(r, lds, spill, make_uint2((unsigned)d2, __float_as_uint(t2)));
+        if (p1) stack_push(r, lds, spill, make_uint2((unsigned)d1, __float_as_uint(t1)));
+    }
     r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 

@@ -13,7 +13,7 @@ namespace rt {
 struct WideRecord {
     float f[16];
 };
-constexpr int WIDE_REF_NONE = 0x40000002;   // slot without a box
+constexpr int WIDE_REF_NONE = 0x40000000;   // slot without a box: the walk's "pop" reference, harmless if ever followed
 
 // Builds the wide tree (DevScene::wnodes) from the two-child tree: node i, its interior children and their children
 // become one record.  Returns false (and the scene renders from the two-box records) when the tree does not qualify:
@@ -108,12 +108,14 @@ inline bool build_wide_nodes(const rt_bvh_node *N, int n_nodes, int top_nodes, i
                 hi = std::max(hi, c.bmax[a]);
             }
             origin[a] = lo;
-            int e = -100;
+            // the grid step is never so small that origin + 255 steps rounds back to the origin: an empty slot's
+            // inverted box (255..0) then misses on every axis the ray moves along
+            int e = std::max(-100, std::ilogb(std::max(std::max(std::fabs(lo), std::fabs(hi)), 1e-30f)) - 22);
             const double extent = (double)hi - (double)lo;
             if (extent > 0) {
                 int ex;
                 (void)frexp(extent / 255.0, &ex);   // 2^ex > extent / 255
-                e = std::max(ex, -100);
+                e = std::max(ex, e);
             }
             for (;; ++e) {   // grid step 2^e: the smallest with which every box fits 0..255
                 if (e > 126) return false;
