@@ -1554,6 +1554,72 @@ void orc_walk_work(long *out) {
     out[0] = g_wide_steps.exchange(0), out[1] = g_wide_leaf_arrivals.exchange(0), out[2] = g_wide_pushes.exchange(0), out[3] = g_wide_maxsp.exchange(0), out[4] = g_two_interior.exchange(0);
 }
 
+// Checks every record of the wide tree against the two-child tree it was built from: each slot's decoded box
+// (fmaf(q, step, origin), the device's arithmetic) contains the exact box of the node it stands for, empty slots are
+// inverted, interior slots lead to the record of that node, leaf slots carry the leaf's entry range, and every leaf is
+// reachable exactly once.  Returns the number of violations (0 = sound), -1 when the scene has no wide tree.
+static int ensure_wide(orc_scene *s) {
+    if (s->wide_state == 0) {
+        float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t;
+        int32_t a, b;
+        orc_intersect_wide(s, o, d, 0.f, 0, 1e-6f, 0, 1e30f, &a, &b, &t);
+    }
+    return s->wide_state;
+}
+long orc_wide_check(orc_scene *s, long *n_records) {
+    if (ensure_wide(s) < 0) return -1;
+    *n_records = (long)s->wide.size();
+    long bad = 0, leaves_seen = 0, leaves = 0;
+    for (const rt_bvh_node &n : s->nodes) leaves += n.n_prims > 0;
+    // walk records and two-child nodes together
+    std::vector<std::pair<int, int>> todo{{0, 0}};   // (record, node)
+    std::vector<char> seen(s->wide.size(), 0);
+    while (!todo.empty()) {
+        const auto [rec, node] = todo.back();
+        todo.pop_back();
+        if (rec < 0 || rec >= (int)s->wide.size() || seen[(size_t)rec]++) {
+            ++bad;
+            continue;
+        }
+        const rt_bvh_node *N = s->nodes.data();
+        const int L = node + 1, R = N[node].offset;
+        int slot[4] = {N[L].n_prims ? L : L + 1, N[L].n_prims ? -1 : N[L].offset, N[R].n_prims ? R : R + 1, N[R].n_prims ? -1 : N[R].offset};
+        unsigned w[16];
+        const float *f = s->wide[(size_t)rec].f;
+        memcpy(w, f, sizeof w);
+        const unsigned sx = w[3] & 0x7f800000u;
+        float step[3];
+        memcpy(&step[0], &sx, 4);
+        step[1] = f[14], step[2] = f[15];
+        const unsigned axes = w[3] & 0x1ffu;
+        const unsigned want_axes = (1u << N[node].axis) | (N[L].n_prims ? 0u : 1u << (3 + N[L].axis)) | (N[R].n_prims ? 0u : 1u << (6 + N[R].axis));
+        if (axes != want_axes) ++bad;
+        for (int k = 0; k < 4; ++k) {
+            const int ref = (int)w[4 + k];
+            for (int a = 0; a < 3; ++a) {
+                const float lo = fmaf((float)((w[8 + 2 * a] >> (8 * k)) & 255u), step[a], f[a]);
+                const float hi = fmaf((float)((w[9 + 2 * a] >> (8 * k)) & 255u), step[a], f[a]);
+                if (slot[k] < 0) {
+                    if (!(lo > hi)) ++bad;
+                } else if (!(lo <= N[slot[k]].bmin[a] && hi >= N[slot[k]].bmax[a])) {
+                    ++bad;
+                }
+            }
+            if (slot[k] < 0) {
+                if (ref != rt::WIDE_REF_NONE) ++bad;
+            } else if (N[slot[k]].n_prims > 0) {
+                ++leaves_seen;
+                if ((unsigned)ref != (0x80000000u | ((unsigned)(N[slot[k]].n_prims - 1) << 24) | (unsigned)N[slot[k]].offset)) ++bad;
+            } else {
+                todo.push_back({ref, slot[k]});
+            }
+        }
+    }
+    if (leaves_seen != leaves) ++bad;
+    for (char c : seen) bad += c != 1;
+    return bad;
+}
+
 // Many rays at once: o, d are n x 3; mode 0 the two-child walk, 1 the wide walk.  Results per ray: shape (-1 none),
 // instance, distance.
 int orc_intersect_many(orc_scene *s, int mode, int n, const float *o, const float *d, const float *stop_t, int any_hit, float eps,

@@ -24,6 +24,13 @@ def lib():
                                         C.POINTER(A.Stats)]
         o.orc_intersect.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_float,
                                     C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        o.orc_intersect_wide.argtypes = o.orc_intersect.argtypes
+        o.orc_intersect_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        o.orc_set_wide.argtypes = [C.c_int]
+        o.orc_walk_mismatches.restype = C.c_long
+        o.orc_wide_check.restype = C.c_long
+        o.orc_wide_check.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         o.orc_math.restype = C.c_float
         o.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
         o.orc_sample_key.restype = C.c_uint32
@@ -68,6 +75,39 @@ class Oracle:
         hit = self._o.orc_intersect(self._ptr, oo, dd, time, int(culling), eps, int(any_hit), stop_t, C.byref(s), C.byref(i),
                                     C.byref(t))
         return bool(hit), s.value, i.value, t.value
+
+    def intersect_many(self, origins, directions, stop_t=None, any_hit=False, eps=1e-6, wide=False):
+        """Rays (n x 3 float32 each) through the two-child walk or, with `wide`, through the product's wide tree walked on
+        the host; returns shape (-1: none), instance and distance per ray."""
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        directions = np.ascontiguousarray(directions, dtype=np.float32)
+        n = len(origins)
+        stop = np.full(n, 1e30, np.float32) if stop_t is None else np.ascontiguousarray(stop_t, dtype=np.float32)
+        shape, inst, t = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32)
+        rc = self._o.orc_intersect_many(self._ptr, int(wide), n, origins.ctypes.data, directions.ctypes.data, stop.ctypes.data,
+                                        int(any_hit), eps, shape.ctypes.data, inst.ctypes.data, t.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("the scene has no wide tree" if rc < 0 else "orc_intersect_many failed")
+        return shape, inst, t
+
+    def wide_check(self):
+        """(violations, records) of the wide tree against the two-child tree; violations -1: no wide tree."""
+        n = C.c_long(0)
+        bad = self._o.orc_wide_check(self._ptr, C.byref(n))
+        return bad, n.value
+
+    def render_comparing_walks(self, cam):
+        """Renders with every ray sent through both walks; returns the image and the number of rays on which the walks
+        disagreed (hit, shape, instance or distance bits)."""
+        before = self._o.orc_walk_mismatches()
+        if self.wide_check()[0] < 0:
+            raise RuntimeError("the scene has no wide tree")
+        self._o.orc_set_wide(2)
+        try:
+            img, st = self.render(cam, threads=1)
+        finally:
+            self._o.orc_set_wide(0)
+        return img, self._o.orc_walk_mismatches() - before
 
     def close(self):
         if self._ptr:
