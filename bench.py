@@ -105,7 +105,7 @@ def kernel_bytes(st, timed):
     }
 
 
-PMC_KERNEL_NAMES = {"generate": "generate_kernel", "trace_closest": "trace_kernel<false, false>", "shade": "shade_kernel<true>",
+PMC_KERNEL_NAMES = {"generate": "generate_kernel", "trace_closest": "trace_kernel<false, false, true>", "trace_any": "trace_kernel<true, false, true>", "shade": "shade_kernel<true>",
                     "light_setup": "light_setup_kernel", "light_gather": "light_gather_kernel", "resolve": "resolve_kernel"}
 
 

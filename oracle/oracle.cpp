@@ -149,6 +149,7 @@ struct Hit {
 };
 
 std::atomic<long> g_walk_mismatches{0};
+std::vector<int> *g_wide_log = nullptr;   // diagnostic: records (>= 0) and leaves (-1 - first entry) a wide walk touches, -2^30 after each ray
 std::atomic<long> g_wide_steps{0}, g_wide_leaf_arrivals{0}, g_wide_leaf_visits{0}, g_two_interior{0}, g_wide_pushes{0}, g_wide_maxsp{0};
 int g_walk_wide = 0;   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
 
@@ -256,6 +257,11 @@ struct Tracer {
     // bvh::intersect, src/bvh.cpp:383-480
     Hit intersect(V o, V d, float time, bool culling, float eps, bool any_hit, float stop_t) {
         if (g_walk_wide == 1 && S.wide_state == 1) return intersect_wide(o, d, time, culling, eps, any_hit, stop_t);
+        if (g_walk_wide == 3 && S.wide_state == 1) {   // logging walk (orc_wide_log)
+            const Hit h = intersect_wide(o, d, time, culling, eps, any_hit, stop_t);
+            if (g_wide_log) g_wide_log->push_back(any_hit ? -(1 << 30) - 1 : -(1 << 30));
+            return h;
+        }
         if (g_walk_wide == 2 && S.wide_state == 1) {   // both walks: report rays on which they disagree
             g_walk_wide = 0;
             const Counters keep = cnt;
@@ -380,10 +386,12 @@ struct Tracer {
                 // quantised boxes only decide what is looked at
                 ++cnt.nodes;
                 ++g_wide_leaf_arrivals;
+                if (g_wide_log) g_wide_log->push_back(-1 - first);
                 if (!slab(S.nodes[(size_t)S.leaf_node_at[(size_t)first]], o, inv, neg, h.t)) {
                     cur = POP;
                     continue;
                 }
+                ++g_wide_leaf_visits;
                 for (int i = 0; i < n; ++i) {
                     const rt_bvh_prim &pr = S.prims[first + i];
                     float tc;
@@ -401,6 +409,7 @@ struct Tracer {
                 continue;
             }
             ++g_wide_steps;
+            if (g_wide_log) g_wide_log->push_back(cur);
             const float *f = S.wide[(size_t)cur].f;
             unsigned w[16];
             memcpy(w, f, sizeof w);
@@ -1551,7 +1560,7 @@ void orc_set_wide(int on) { g_walk_wide = on; }
 long orc_walk_mismatches(void) { return g_walk_mismatches.load(); }
 // work of the walks since the last call: wide steps, leaves reached by the wide walk, pushes, deepest stack, interior nodes expanded by the two-child walk
 void orc_walk_work(long *out) {
-    out[0] = g_wide_steps.exchange(0), out[1] = g_wide_leaf_arrivals.exchange(0), out[2] = g_wide_pushes.exchange(0), out[3] = g_wide_maxsp.exchange(0), out[4] = g_two_interior.exchange(0);
+    out[0] = g_wide_steps.exchange(0), out[1] = g_wide_leaf_arrivals.exchange(0), out[2] = g_wide_pushes.exchange(0), out[3] = g_wide_maxsp.exchange(0), out[4] = g_two_interior.exchange(0), out[5] = g_wide_leaf_visits.exchange(0);
 }
 
 // Checks every record of the wide tree against the two-child tree it was built from: each slot's decoded box
@@ -1618,6 +1627,31 @@ long orc_wide_check(orc_scene *s, long *n_records) {
     if (leaves_seen != leaves) ++bad;
     for (char c : seen) bad += c != 1;
     return bad;
+}
+
+// Copies the wide records (16 words each) to `out` (room for `n_records`); returns their number.
+long orc_wide_records(orc_scene *s, float *out, long n_records) {
+    if (ensure_wide(s) < 0) return -1;
+    const long n = std::min<long>(n_records, (long)s->wide.size());
+    if (out) memcpy(out, s->wide.data(), (size_t)n * sizeof(rt::WideRecord));
+    return (long)s->wide.size();
+}
+
+// Diagnostic for layout studies: walks a render's rays through the wide tree (single thread) and returns what each
+// ray touched; `out` receives up to `room` entries (records >= 0, leaves -1 - first entry, -2^30 ends a ray).
+long orc_wide_log(orc_scene *s, const rt_camera_desc *cam, int32_t *out, long room) {
+    if (ensure_wide(s) < 0) return -1;
+    std::vector<int> log;
+    std::vector<float> img((size_t)cam->resx * cam->resy * 3);
+    rt_stats st;
+    g_wide_log = &log;
+    g_walk_wide = 3;
+    orc_render(s, cam, img.data(), &st, 1);
+    g_walk_wide = 0;
+    g_wide_log = nullptr;
+    const long n = std::min<long>(room, (long)log.size());
+    memcpy(out, log.data(), (size_t)n * 4);
+    return n;
 }
 
 // Many rays at once: o, d are n x 3; mode 0 the two-child walk, 1 the wide walk.  Results per ray: shape (-1 none),

@@ -370,21 +370,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         } else if (n_leaf) {
             if (r.cur < 0) {
                 const int k = r.cur & 0xffffff;
+                const float4 p2 = S.prims[PRIM_STRIDE * (size_t)k + 2];
                 bool inside = true;
                 if (WIDE && fresh) {
                     // The quantised boxes decide what the walk looks at; whether a leaf's entries are tested is decided by
                     // the leaf's own box, as in the two-box walk.  (A ray that passes the leaf's box passes the boxes of
-                    // all its ancestors, which contain it, so this one test stands for the whole chain.)
+                    // all its ancestors, which contain it, so this one test stands for the whole chain.)  The box sits in
+                    // the entry's own 64-byte block.
                     fresh = false;
-                    const float4 b0 = S.leaf_boxes[2 * (size_t)k], b1 = S.leaf_boxes[2 * (size_t)k + 1];
+                    const float4 p3 = S.prims[PRIM_STRIDE * (size_t)k + 3];
                     float tm;
-                    inside = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0, r.iy < 0, r.iz < 0, tm) && tm < r.t;
+                    inside = slab(p2.z, p2.w, p3.x, p3.y, p3.z, p3.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0, r.iy < 0, r.iz < 0, tm) && tm < r.t;
                     if (!inside) r.cur = REF_POP;
                 }
                 if (inside) {
                     float tc;
                     bool done = false;
-                    if (prim_test<COUNT>(S, k, r, eps, tc, c) && tc > eps && tc < r.t) {
+                    if (prim_test<COUNT>(S, k, p2, r, eps, tc, c) && tc > eps && tc < r.t) {
                         r.t = tc;
                         r.prim = k;
                         done = ANY;
@@ -1101,9 +1103,9 @@ __global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_
         if (prim <= -2) {
             shape = S.n_triangles + S.n_spheres + (-2 - prim);
         } else if (prim >= 0) {
-            const float4 p2 = S.prims[PRIM_STRIDE * (size_t)prim + 2];
-            shape = __float_as_int(p2.z);
-            id = __float_as_int(p2.w);
+            const int4 meta = S.prim_meta[(size_t)prim];
+            shape = meta.y;
+            id = meta.z;
         }
         shape_out[px] = shape;
         id_out[px] = id;
@@ -1537,6 +1539,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     const bool has_wide = build_wide_nodes(d->bvh_nodes, d->n_bvh_nodes, TOP_NODES, LDS_STACK + SPILL_STACK, wnodes, wroot_ref, n_wtop);
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
+    std::vector<int4> prim_meta((size_t)d->n_bvh_prims);
     auto as_float = [](int v) {
         float f;
         memcpy(&f, &v, 4);
@@ -1556,11 +1559,22 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             prims[PRIM_STRIDE * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
             const rt_instance &in = d->instances[p.instance];
             const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
-            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), as_float(p.shape), as_float(in.ref_id));
+            prim_meta[i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, 0);
+            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(prim_meta[i].x), 0.f, 0.f);
         } else {
             prims[PRIM_STRIDE * i] = make_float4(0, 0, 0, 0);
             prims[PRIM_STRIDE * i + 1] = make_float4(0, 0, 0, 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(-1 - (p.shape - d->n_triangles)), as_float(p.shape), as_float(123456));
+            prim_meta[i] = make_int4(-1 - (p.shape - d->n_triangles), p.shape, 123456, 0);
+            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(prim_meta[i].x), 0.f, 0.f);
+        }
+        prims[PRIM_STRIDE * i + 3] = make_float4(0, 0, 0, 0);
+    }
+    for (int i = 0; i < d->n_bvh_nodes; ++i) {   // every entry carries the box of its leaf
+        const rt_bvh_node &n = d->bvh_nodes[i];
+        for (int k = 0; k < n.n_prims; ++k) {
+            float4 *e = &prims[PRIM_STRIDE * (size_t)(n.offset + k)];
+            e[2].z = n.bmin[0], e[2].w = n.bmin[1];
+            e[3] = make_float4(n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]);
         }
     }
     std::vector<float4> inst((size_t)d->n_instances * 4);
@@ -1600,22 +1614,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         keep(tmp_);                                                                   \
     } while (0)
     UP(nodes, nodes.data(), nodes.size());
-    std::vector<float4> leaf_boxes;   // per first leaf entry: the leaf's own box {min.xyz, max.x} {max.yz, 0, 0}
     if (has_wide) {
-        leaf_boxes.assign((size_t)d->n_bvh_prims * 2, make_float4(0, 0, 0, 0));
-        for (int i = 0; i < d->n_bvh_nodes; ++i) {
-            const rt_bvh_node &n = d->bvh_nodes[i];
-            if (n.n_prims == 0) continue;
-            leaf_boxes[2 * (size_t)n.offset] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], n.bmax[0]);
-            leaf_boxes[2 * (size_t)n.offset + 1] = make_float4(n.bmax[1], n.bmax[2], 0.f, 0.f);
-        }
-        UP(leaf_boxes, leaf_boxes.data(), leaf_boxes.size());
         static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
         UP(wnodes, (const float4 *)wnodes.data(), wnodes.size() * 4);
         D.wroot_ref = wroot_ref;
         D.n_wtop = n_wtop;
     }
     UP(prims, prims.data(), prims.size());
+    UP(prim_meta, prim_meta.data(), prim_meta.size());
     UP(inst, inst.data(), inst.size());
     UP(instances, d->instances, d->n_instances);
     UP(triangles, d->triangles, d->n_triangles);

@@ -22,9 +22,11 @@ enum {
 // nodes:  4 x float4 per INTERIOR BVH node, holding the boxes of both children:
 //         {Lmin.xyz, Lmax.x} {Lmax.yz, Rmin.xy} {Rmin.z, Rmax.xyz} {bits(Lref), bits(Rref), bits(1 << split axis), 0}
 //         child ref >= 0: interior node index; < 0: leaf = 1<<31 | (n_prims - 1) << 24 | first leaf entry
-// prims:  3 x float4 per leaf entry, in leaf order:
-//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), bits(shape), bits(ref id)}
-//         sphere   {...unused...}                 {0, bits(-1 - sphere), bits(shape), bits(123456)}
+// prims:  4 x float4 (one 64-byte block) per leaf entry, in leaf order; the last 24 bytes hold the box of the leaf the
+//         entry belongs to, so that the wide walk's exact leaf test and the first entry's test read the same block:
+//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), leaf min.xy} {leaf min.z, leaf max.xyz}
+//         sphere   {...unused...}                 {0, bits(-1 - sphere), leaf min.xy} {leaf min.z, leaf max.xyz}
+// prim_meta: per leaf entry {bits(instance) as above, shape, reference id, 0}: what shading needs of a hit entry
 // inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
 //         flags bit0 = identity transform, bit1 = has motion blur
 // wnodes: 4 x float4 per WIDE node: an interior node merged with those of its two children that are interior, so
@@ -36,8 +38,8 @@ enum {
 struct DevScene {
     const float4 *nodes;
     const float4 *wnodes;   // null when the scene has no wide tree
-    const float4 *leaf_boxes;   // with a wide tree, per first leaf entry k: the leaf's own box {min.xyz, max.x} {max.yz, -, -} at [2k]
     const float4 *prims;
+    const int4 *prim_meta;
     const float4 *inst;
     const rt_instance *instances;
     const rt_triangle *triangles;
@@ -97,10 +99,7 @@ constexpr int LDS_STACK = RT_LDS_STACK;
 constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
 constexpr int REF_POP = 0x40000000;
 constexpr int REF_IDLE = 0x40000001;
-#ifndef RT_PRIM_STRIDE
-#define RT_PRIM_STRIDE 4
-#endif
-constexpr int PRIM_STRIDE = RT_PRIM_STRIDE;   // float4 per leaf entry: 3 used; 4 keeps an entry inside one 64-byte block
+constexpr int PRIM_STRIDE = 4;   // float4 per leaf entry: one 64-byte block
 constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's placement index: the placement moves or transforms the ray
 
 // Box test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance.  The
@@ -343,8 +342,7 @@ __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const u
 
 // Leaf entry k against the ray; true with the distance in `tc` when the primitive reports a hit (t > eps).
 template <bool COUNT>
-__device__ __forceinline__ bool prim_test(const DevScene &S, int k, const RayState &r, float eps, float &tc, Counters &c) {
-    const float4 p2 = S.prims[PRIM_STRIDE * (size_t)k + 2];
+__device__ __forceinline__ bool prim_test(const DevScene &S, int k, float4 p2, const RayState &r, float eps, float &tc, Counters &c) {   // p2 = S.prims[4 k + 2]
     const int inst = __float_as_int(p2.y);
     if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
         if (COUNT) ++c.tri;
@@ -436,12 +434,12 @@ __device__ Surface surface_of(const DevScene &S, const Hit &h) {
         s.tcount = p.tex_count;
         return s;
     }
-    const float4 p2 = S.prims[PRIM_STRIDE * (size_t)h.prim + 2];
-    int inst = __float_as_int(p2.y);
+    const int4 meta = S.prim_meta[(size_t)h.prim];
+    int inst = meta.x;
     if (inst >= 0) {
         inst &= ~PRIM_XFORM_BIT;
         s.kind = 0;
-        s.index = __float_as_int(p2.z);
+        s.index = meta.y;
         s.instance = inst;
         const rt_instance &in = S.instances[inst];
         s.material = in.material;
