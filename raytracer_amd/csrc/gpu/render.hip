@@ -370,7 +370,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         } else if (n_leaf) {
             if (r.cur < 0) {
                 const int k = r.cur & 0xffffff;
-                const float4 p2 = S.prims[PRIM_STRIDE * (size_t)k + 2];
+                const float4 *entry = S.prims + PRIM_STRIDE * (size_t)k;   // one 64-byte block, read at once
+                const float4 p0 = entry[0], p1 = entry[1], p2 = entry[2];
                 bool inside = true;
                 if (WIDE && fresh) {
                     // The quantised boxes decide what the walk looks at; whether a leaf's entries are tested is decided by
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                     // all its ancestors, which contain it, so this one test stands for the whole chain.)  The box sits in
                     // the entry's own 64-byte block.
                     fresh = false;
-                    const float4 p3 = S.prims[PRIM_STRIDE * (size_t)k + 3];
+                    const float4 p3 = entry[3];
                     float tm;
                     inside = slab(p2.z, p2.w, p3.x, p3.y, p3.z, p3.w, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.ix < 0, r.iy < 0, r.iz < 0, tm) && tm < r.t;
                     if (!inside) r.cur = REF_POP;
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 if (inside) {
                     float tc;
                     bool done = false;
-                    if (prim_test<COUNT>(S, k, p2, r, eps, tc, c) && tc > eps && tc < r.t) {
+                    if (prim_test<COUNT>(S, p0, p1, p2, r, eps, tc, c) && tc > eps && tc < r.t) {
                         r.t = tc;
                         r.prim = k;
                         done = ANY;

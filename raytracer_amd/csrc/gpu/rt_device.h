@@ -342,11 +342,11 @@ __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const u
 
 // Leaf entry k against the ray; true with the distance in `tc` when the primitive reports a hit (t > eps).
 template <bool COUNT>
-__device__ __forceinline__ bool prim_test(const DevScene &S, int k, float4 p2, const RayState &r, float eps, float &tc, Counters &c) {   // p2 = S.prims[4 k + 2]
+// p0, p1, p2: the first three float4 of the entry (loaded by the caller, together with the leaf's box where it needs it)
+__device__ __forceinline__ bool prim_test(const DevScene &S, float4 p0, float4 p1, float4 p2, const RayState &r, float eps, float &tc, Counters &c) {
     const int inst = __float_as_int(p2.y);
     if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
         if (COUNT) ++c.tri;
-        const float4 p0 = S.prims[PRIM_STRIDE * (size_t)k], p1 = S.prims[PRIM_STRIDE * (size_t)k + 1];
         const V ro = mk(r.ox, r.oy, r.oz), rd = mk(r.dx, r.dy, r.dz);
         V oo = ro, dd = rd;
         if (inst & PRIM_XFORM_BIT) {
