@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
             if ((unsigned)r.cur < (unsigned)REF_POP) {
                 if (WIDE) {
                     wide_step(S, r, lds, spill, top_nodes, n_top);
+#ifndef RT_NO_INLINE_POP
+                    if (r.cur == REF_POP) pop_inline<!ANY>(r, lds);
+#endif
                     fresh = true;
                 } else
                     node_step<COUNT>(S, r, lds, spill, top_nodes, n_top, c);
@@ -399,6 +402,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                         r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
                     }
                 }
+#ifndef RT_NO_INLINE_POP
+                if (WIDE && r.cur == REF_POP) {
+                    pop_inline<!ANY>(r, lds);
+                    fresh = true;
+                }
+#endif
             }
         }
     }
