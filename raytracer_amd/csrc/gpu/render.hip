@@ -61,10 +61,12 @@ thread_local std::string g_error;
 // added to a slot, and a slot's random numbers depend only on (seed, pixel, sample, path node).
 // =====================================================================================================
 
-// waves per SIMD of the trace kernel: 5 measured fastest (4: 475 ms, 5: 426 ms, 6: 438 ms, 7: 459 ms, 8: 467 ms of closest-hit
-// time per 4K / 64 spp frame of the 1M-triangle scene) -- more waves evict each other's part of the tree from the caches
+// waves per SIMD of the trace kernel, measured (closest-hit time per 4K / 64 spp frame of the 1M-triangle scene).  With the
+// two-box records 5 was fastest (4: 475 ms, 5: 426, 6: 438, 7: 459, 8: 467: more waves evict each other's part of the tree
+// from the caches); the wide tree moves less data per ray and gains from a sixth wave (4: 307 ms, 5: 273, 6: 255), which
+// is what 82 registers and 26 KB of LDS per workgroup (stack 22 KB + top of the tree 4 KB) allow
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 5
+#define RT_TRACE_WAVES 6
 #endif
 constexpr int MAX_GENERATIONS = 66;   // queue generations per batch (depth limit + 2)
 
