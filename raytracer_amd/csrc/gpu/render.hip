@@ -366,7 +366,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 if (WIDE) {
                     wide_step(S, r, lds, spill, top_nodes, n_top);
 #ifndef RT_NO_INLINE_POP
-                    if (r.cur == REF_POP) pop_inline<!ANY>(r, lds);
+                    if (r.cur == REF_POP && pop_inline<!ANY>(r, lds)) {
+                        ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
+                        r.cur = REF_IDLE;
+                    }
 #endif
                     fresh = true;
                 } else
@@ -406,7 +409,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 }
 #ifndef RT_NO_INLINE_POP
                 if (WIDE && r.cur == REF_POP) {
-                    pop_inline<!ANY>(r, lds);
+                    if (pop_inline<!ANY>(r, lds)) {
+                        ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
+                        r.cur = REF_IDLE;
+                    }
                     fresh = true;
                 }
 #endif
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         }
     }
 #ifdef RT_TRACE_PROFILE
-    if (!ANY && lane == 0) {
+    if (ANY == (RT_TRACE_PROFILE == 2) && lane == 0) {   // 1: the closest-hit kernel's waves, 2: the any-hit kernel's
         unsigned long long *row = stats + (blockIdx.x % STAT_ROWS) * STAT_WORDS;
         const unsigned vals[8] = {pf_node_it, pf_node_ln, pf_leaf_it, pf_leaf_ln, pf_pop_it, pf_pop_ln, pf_it, pf_busy};
         for (int k = 0; k < 4; ++k) atomicAdd(row + 3 + k, (unsigned long long)vals[k]);

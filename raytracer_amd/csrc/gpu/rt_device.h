@@ -343,14 +343,17 @@ __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const u
 
 // One pop without the loop, for a lane that has just finished its node inside a step: takes the top entry when it
 // lies in the LDS part of the stack; an entry that no longer qualifies is dropped and the lane stays at REF_POP, which
-// the next round of stack_pop continues from -- the same entries are taken in the same order.
+// the next round of stack_pop continues from -- the same entries are taken in the same order.  Returns true when the
+// stack was empty: the ray is finished.
 template <bool CHECK>
-__device__ __forceinline__ void pop_inline(RayState &r, const uint2 *lds) {
-    if (r.sp > 0 && r.sp <= LDS_STACK) {
+__device__ __forceinline__ bool pop_inline(RayState &r, const uint2 *lds) {
+    if (r.sp == 0) return true;
+    if (r.sp <= LDS_STACK) {
         const uint2 e = lds[(r.sp - 1) * STACK_STRIDE];
         --r.sp;
         if (!CHECK || __uint_as_float(e.y) < r.t) r.cur = (int)e.x;
     }
+    return false;
 }
 
 // Leaf entry k against the ray; true with the distance in `tc` when the primitive reports a hit (t > eps).

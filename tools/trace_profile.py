@@ -13,5 +13,5 @@ it = d['any_hit_sphere_tests']
 print('wave iterations', it, 'busy lanes per iteration %.1f' % (d['any_hit_plane_tests'] / it))
 for name, a, b in (('node', 'nodes_visited', 'triangle_tests'), ('leaf', 'sphere_tests', 'plane_tests'), ('pop', 'any_hit_nodes_visited', 'any_hit_triangle_tests')):
     print(f"{name}: in {d[a] / it:.3f} of the iterations, {d[b] / max(1, d[a]):.1f} lanes each")
-rays = d['primary_rays'] + d['secondary_rays']
+rays = d['shadow_rays_traced'] if len(sys.argv) > 1 and sys.argv[1] == 'any' else d['primary_rays'] + d['secondary_rays']
 print('per ray: node steps %.2f leaf steps %.2f pops %.2f' % (d['triangle_tests'] / rays, d['plane_tests'] / rays, d['any_hit_triangle_tests'] / rays))
