@@ -1637,6 +1637,15 @@ long orc_wide_records(orc_scene *s, float *out, long n_records) {
     return (long)s->wide.size();
 }
 
+// Builds the wide tree again and returns the milliseconds the product's builder took (host-side cost of a scene).
+double orc_wide_build_ms(orc_scene *s) {
+    std::vector<rt::WideRecord> out;
+    int root = 0, n_top = 0;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    rt::build_wide_nodes(s->nodes.data(), (int)s->nodes.size(), 63, 64, out, root, n_top);
+    return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+}
+
 // Diagnostic for layout studies: walks a render's rays through the wide tree (single thread) and returns what each
 // ray touched; `out` receives up to `room` entries (records >= 0, leaves -1 - first entry, -2^30 ends a ray).
 long orc_wide_log(orc_scene *s, const rt_camera_desc *cam, int32_t *out, long room) {

@@ -1171,6 +1171,11 @@ struct rt_scene {
     float *framebuffer = nullptr;
     size_t framebuffer_floats = 0;
     bool counters = false;
+    // The wide tree costs host time to build (about 50 ms per million BVH nodes) and saves device time per ray, so it is
+    // built when the scene has been asked for enough rays to repay it; until then the two-box records serve.
+    // RT_WIDE_NODES=1: at scene creation, =0: never.
+    std::vector<rt_bvh_node> host_nodes;   // kept while the wide tree may still be built
+    unsigned long long paths_seen = 0;
     int device = 0;
     hipStream_t stream = nullptr;    // generate, closest-hit trace, shade, resolve
     hipStream_t stream2 = nullptr;   // direct lighting (light setup, any-hit trace, gather)
@@ -1370,9 +1375,8 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned sha
 // (the grid a one-ray-per-lane launch would use; small batches need fewer workgroups than the chip holds).
 static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned grid_limit, int gen, int whitted) {
     const bool count = s->counters;
-    // the wide tree serves every render without counters; RT_WIDE_NODES=0 keeps the two-box records (A/B timing)
-    static const bool wide_env = !(getenv("RT_WIDE_NODES") && atoi(getenv("RT_WIDE_NODES")) == 0);
-    const bool wide = !count && wide_env && s->dev.wnodes != nullptr;
+    // the wide tree, once built, serves every render without counters
+    const bool wide = !count && s->dev.wnodes != nullptr;
     typedef void (*TraceFn)(DevScene, Wavefront, int, int, TraceTuning, unsigned long long *);
     const TraceFn fn = wide    ? (any ? trace_kernel<true, false, true> : trace_kernel<false, false, true>)
                        : count ? (any ? trace_kernel<true, true, false> : trace_kernel<false, true, false>)
@@ -1394,6 +1398,37 @@ static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned gri
         return t;
     }();
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
+}
+
+// Builds and uploads the wide tree from the kept copy of the BVH (which is released either way).  A tree that does not
+// qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
+static int build_wide_tree(rt_scene *s) {
+    std::vector<rt_bvh_node> nodes;
+    nodes.swap(s->host_nodes);
+    if (nodes.empty()) return 0;
+    std::vector<WideRecord> records;   // 64 bytes each, read as 4 x float4 on the device
+    int root_ref = 0, n_top = 0;
+    if (!build_wide_nodes(nodes.data(), (int)nodes.size(), TOP_NODES, LDS_STACK + SPILL_STACK, records, root_ref, n_top)) return 0;
+    static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
+    float4 *dev = nullptr;
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipMalloc((void **)&dev, records.size() * sizeof(WideRecord)));
+    s->allocations.push_back(dev);
+    HIP_OK(hipMemcpy(dev, records.data(), records.size() * sizeof(WideRecord), hipMemcpyHostToDevice));
+    s->dev.wroot_ref = root_ref;
+    s->dev.n_wtop = n_top;
+    s->dev.wnodes = dev;
+    return 0;
+}
+
+// Called by every render with the number of camera paths it is about to trace: the wide tree is built once the scene
+// has been asked for 64 paths per BVH node (a 70 K-triangle scene: one 4K frame or four 1080p frames at 1 spp; the
+// 1M-triangle scene: 110 M paths, a twentieth of its 4K / 256 spp frame).
+static int account_paths(rt_scene *s, unsigned long long paths) {
+    if (s->host_nodes.empty()) return 0;
+    s->paths_seen += paths;
+    if (s->paths_seen < 64ull * s->host_nodes.size()) return 0;
+    return build_wide_tree(s);
 }
 
 extern "C" {
@@ -1552,9 +1587,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             return 3;
         }
     }
-    std::vector<WideRecord> wnodes;   // 64 bytes each, read as 4 x float4 on the device
-    int wroot_ref = 0, n_wtop = 0;
-    const bool has_wide = build_wide_nodes(d->bvh_nodes, d->n_bvh_nodes, TOP_NODES, LDS_STACK + SPILL_STACK, wnodes, wroot_ref, n_wtop);
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
     std::vector<int4> prim_meta((size_t)d->n_bvh_prims);
@@ -1632,12 +1664,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         keep(tmp_);                                                                   \
     } while (0)
     UP(nodes, nodes.data(), nodes.size());
-    if (has_wide) {
-        static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
-        UP(wnodes, (const float4 *)wnodes.data(), wnodes.size() * 4);
-        D.wroot_ref = wroot_ref;
-        D.n_wtop = n_wtop;
-    }
     UP(prims, prims.data(), prims.size());
     UP(prim_meta, prim_meta.data(), prim_meta.size());
     UP(inst, inst.data(), inst.size());
@@ -1660,6 +1686,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     D.n_lights = d->n_lights;
     D.n_nodes = d->n_bvh_nodes;
     D.root_ref = root_ref;
+    {
+        const char *e = getenv("RT_WIDE_NODES");
+        const int mode = e ? atoi(e) : -1;
+        if (mode != 0 && d->n_bvh_nodes >= 3 && d->bvh_nodes[0].n_prims == 0) s->host_nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
+        if (mode > 0 && build_wide_tree(s) != 0) {
+            rt_scene_destroy(s);
+            return 10;
+        }
+    }
     if (d->n_bvh_nodes > 0) {
         memcpy(D.root_min, d->bvh_nodes[0].bmin, sizeof D.root_min);
         memcpy(D.root_max, d->bvh_nodes[0].bmax, sizeof D.root_max);
@@ -1834,6 +1869,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_OK(hipSetDevice(s->device));
+    if (int rc = account_paths(s, (unsigned long long)cam->resx * cam->resy * n_samples / world)) return rc;
     const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
     const int total_tiles = tiles_x * tiles_y;
     const int n_owned = total_tiles > rank ? (total_tiles - rank + world - 1) / world : 0;
@@ -2007,6 +2043,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     int grid_n, n_samples;
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
     HIP_OK(hipSetDevice(s->device));
+    if (int rc = account_paths(s, (unsigned long long)cam->resx * cam->resy)) return rc;
     const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
     const int total_tiles = tiles_x * tiles_y;
     if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull, 1, 0)) return rc;

@@ -20,7 +20,8 @@ def path_of(name, scene_dir):
 
 
 @pytest.mark.parametrize("name", list(GS.SCENES) + ["mesh70k", "pt1m"])
-def test_wide_walk_equals_two_box_walk(name, scene_dir):
+def test_wide_walk_equals_two_box_walk(name, scene_dir, monkeypatch):
+    monkeypatch.setenv("RT_WIDE_NODES", "1")   # read at scene creation: the wide tree now, not after enough rays
     sc = R.Scene(path_of(name, scene_dir))
     cam = sc.camera(0)
     ren = R.Renderer(sc)
@@ -36,3 +37,21 @@ def test_wide_walk_equals_two_box_walk(name, scene_dir):
     # images: the same paths, summed by float atomics in a different order
     err = np.abs(img_w - img_2) / np.maximum(np.abs(img_2), 1 / 255)
     assert err.max() <= 1e-5
+
+
+def test_the_switch_to_the_wide_tree_is_invisible(scene_dir, monkeypatch):
+    """By default a scene gets its wide tree once it has been asked for 64 camera paths per BVH node (building it costs
+    host time that few rays do not repay): the 70 K-triangle scene changes walks with its fourth 1080p frame.  The
+    frames before and after are the same."""
+    monkeypatch.delenv("RT_WIDE_NODES", raising=False)
+    sc = R.Scene(path_of("mesh70k", scene_dir))
+    assert 3 * 1920 * 1080 < 64 * sc.desc.n_bvh_nodes < 4 * 1920 * 1080      # the fourth frame is the first on the wide tree
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    frames = [ren.render(cam)[0] for _ in range(7)]
+    for f in frames[1:]:
+        assert np.abs(f - frames[0]).max() <= 1e-5 * max(1.0, float(frames[0].max()))
+    ids = [ren.trace_primary(cam) for _ in range(2)]
+    ren.set_counters(True)
+    shape_2, id_2, t_2, _ = ren.trace_primary(cam)
+    assert np.array_equal(ids[1][0], shape_2) and np.array_equal(ids[1][2].view(np.uint32), t_2.view(np.uint32))

@@ -1,6 +1,7 @@
 """Diagnostic (library built with -DRT_TRACE_PROFILE): how the closest-hit trace kernel's wave iterations split into
 node / leaf / pop steps and how many lanes take part in each."""
-import sys
+import os, sys
+os.environ.setdefault('RT_WIDE_NODES', '1')
 sys.path.insert(0, '.')
 import raytracer_amd as R
 from raytracer_amd import scenegen

@@ -1,6 +1,7 @@
 """Wide-tree walk against the two-box walk on the GPU: images, primary hit ids and distances of the fixture scenes
 and of the two benchmark meshes (reduced).  The counted render walks the two-box records."""
 import sys, os
+os.environ.setdefault('RT_WIDE_NODES', '1')
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import raytracer_amd as R
