@@ -20,6 +20,12 @@
 //    mapping); Perlin textures always see the current hit point.
 //  * instance inverse matrices come from the host ingest (exact cofactor inverse), not from the
 //    reference's rcp-based Cramer inverse (src/algebra.cpp:246-370).
+//
+// Besides the reference's walk (Tracer::intersect) the library can walk the PRODUCT's wide tree on the host
+// (Tracer::intersect_wide over the records of raytracer_amd/csrc/gpu/rt_wide.h, the one product header it includes):
+// orc_wide_check validates the records against the two-child tree, orc_intersect_many / orc_set_wide(2) compare the
+// two walks ray by ray.  That checks the product's data structure with the checker's own primitive tests; the product
+// does not use any of it.
 // Compile with -ffp-contract=off and without fast-math.
 #include <algorithm>
 #include <atomic>
@@ -150,7 +156,8 @@ struct Hit {
 
 std::atomic<long> g_walk_mismatches{0};
 std::vector<int> *g_wide_log = nullptr;   // diagnostic: records (>= 0) and leaves (-1 - first entry) a wide walk touches, -2^30 after each ray
-std::atomic<long> g_wide_steps{0}, g_wide_leaf_arrivals{0}, g_wide_leaf_visits{0}, g_two_interior{0}, g_wide_pushes{0}, g_wide_maxsp{0};
+// work of the walks on the calling thread (read by orc_walk_work after a single-threaded render)
+thread_local long g_wide_steps = 0, g_wide_leaf_arrivals = 0, g_wide_leaf_visits = 0, g_two_interior = 0, g_wide_pushes = 0, g_wide_maxsp = 0;
 int g_walk_wide = 0;   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
 
 struct Tracer {
@@ -1558,9 +1565,12 @@ int orc_intersect_wide(orc_scene *s, const float *o, const float *d, float time,
 // builds it); counters then count the root box only.  For checking that both walks give the same image.
 void orc_set_wide(int on) { g_walk_wide = on; }
 long orc_walk_mismatches(void) { return g_walk_mismatches.load(); }
-// work of the walks since the last call: wide steps, leaves reached by the wide walk, pushes, deepest stack, interior nodes expanded by the two-child walk
+// work of the walks on the calling thread since the last call (render with one thread): wide steps, leaves reached by
+// the wide walk, pushes, deepest stack, interior nodes expanded by the two-child walk, leaves whose exact box passed
 void orc_walk_work(long *out) {
-    out[0] = g_wide_steps.exchange(0), out[1] = g_wide_leaf_arrivals.exchange(0), out[2] = g_wide_pushes.exchange(0), out[3] = g_wide_maxsp.exchange(0), out[4] = g_two_interior.exchange(0), out[5] = g_wide_leaf_visits.exchange(0);
+    const long v[6] = {g_wide_steps, g_wide_leaf_arrivals, g_wide_pushes, g_wide_maxsp, g_two_interior, g_wide_leaf_visits};
+    memcpy(out, v, sizeof v);
+    g_wide_steps = g_wide_leaf_arrivals = g_wide_pushes = g_wide_maxsp = g_two_interior = g_wide_leaf_visits = 0;
 }
 
 // Checks every record of the wide tree against the two-child tree it was built from: each slot's decoded box
