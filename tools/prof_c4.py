@@ -1,4 +1,5 @@
-import sys
+import os, sys
+os.environ.setdefault("RT_WIDE_NODES", "1")
 sys.path.insert(0,'.')
 import raytracer_amd as R
 from raytracer_amd import scenegen
