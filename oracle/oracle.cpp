@@ -1647,6 +1647,14 @@ long orc_wide_records(orc_scene *s, float *out, long n_records) {
     return (long)s->wide.size();
 }
 
+// The product's builder on a caller-made two-child tree (for trees an ingest would not produce): number of records,
+// -1 when the builder declines the tree.
+long orc_wide_build_raw(const rt_bvh_node *nodes, int n_nodes, int stack_entries) {
+    std::vector<rt::WideRecord> out;
+    int root = 0, n_top = 0;
+    return rt::build_wide_nodes(nodes, n_nodes, 63, stack_entries, out, root, n_top) ? (long)out.size() : -1;
+}
+
 // Builds the wide tree again and returns the milliseconds the product's builder took (host-side cost of a scene).
 double orc_wide_build_ms(orc_scene *s) {
     std::vector<rt::WideRecord> out;

@@ -72,3 +72,44 @@ def test_a_render_never_sees_the_walks_disagree(name, scene_dir):
     cam = sc.camera(0, num_samples=4)
     img, disagreements = Oracle(sc).render_comparing_walks(cam)
     assert disagreements == 0 and np.isfinite(img).all()
+
+
+def chain_tree(depth, bad_box=False):
+    """A two-child tree that is one long chain: every interior node has a leaf on the left and the rest on the right."""
+    import ctypes as C
+    from raytracer_amd import _abi as A
+    n = 2 * depth + 1
+    nodes = (A.BvhNode * n)()
+    for d in range(depth):
+        i = 2 * d
+        lo, hi = float(d), float(depth + 1)
+        for node, (a, b) in ((nodes[i], (lo, hi)), (nodes[i + 1], (lo, lo + 1.0))):
+            for k in range(3):
+                node.bmin[k], node.bmax[k] = a, b
+        nodes[i].n_prims, nodes[i].offset, nodes[i].axis = 0, i + 2, d % 3
+        nodes[i + 1].n_prims, nodes[i + 1].offset = 1, d
+    last = nodes[n - 1]
+    for k in range(3):
+        last.bmin[k], last.bmax[k] = float(depth), float(depth + 1)
+    last.n_prims, last.offset = 1, depth
+    if bad_box:
+        nodes[3].bmax[1] = float("inf")
+    return nodes, n
+
+
+def test_builder_declines_what_the_walk_cannot_hold():
+    """The walk's stack has the reference's 64 entries (src/bvh.cpp:423).  A record leaves up to three entries waiting, so a
+    tree whose wide walk could need more than 64 is declined (the scene then renders from the two-box records), as is a
+    tree with a box that is not finite."""
+    from oracle_lib import lib
+    import ctypes as C
+    L = lib()
+    L.orc_wide_build_raw.restype = C.c_long
+    L.orc_wide_build_raw.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    nodes, n = chain_tree(40)
+    assert L.orc_wide_build_raw(nodes, n, 64) == 20          # two chain links per record
+    nodes, n = chain_tree(400)
+    assert L.orc_wide_build_raw(nodes, n, 64) == -1          # 200 records deep, one entry waiting at each
+    assert L.orc_wide_build_raw(nodes, n, 1000) == 200
+    nodes, n = chain_tree(40, bad_box=True)
+    assert L.orc_wide_build_raw(nodes, n, 64) == -1
