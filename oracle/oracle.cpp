@@ -142,6 +142,7 @@ struct orc_scene {
     // the product's wide tree (raytracer_amd/csrc/gpu/rt_wide.h), built on demand by orc_intersect_wide
     std::vector<rt::WideRecord> wide;
     std::vector<int> leaf_node_at;   // first leaf entry -> the leaf's node
+    std::vector<int> wide_slot_node;   // study: record * 4 + slot -> two-child node (-1 empty), filled by orc_wide_check
     int wide_state = 0;   // 0 not built yet, 1 built, -1 the tree does not qualify
 };
 
@@ -158,7 +159,8 @@ std::atomic<long> g_walk_mismatches{0};
 std::vector<int> *g_wide_log = nullptr;   // diagnostic: records (>= 0) and leaves (-1 - first entry) a wide walk touches, -2^30 after each ray
 // work of the walks on the calling thread (read by orc_walk_work after a single-threaded render)
 thread_local long g_wide_steps = 0, g_wide_leaf_arrivals = 0, g_wide_leaf_visits = 0, g_two_interior = 0, g_wide_pushes = 0, g_wide_maxsp = 0;
-int g_walk_wide = 0;   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
+int g_walk_wide = 0;
+int g_walk_exact_slots = 0;   // study: the wide walk tests the slots' exact boxes instead of the quantised ones (what does 8 bits cost?)   // orc_set_wide: renders walk the product's wide tree instead of the two-child tree
 
 struct Tracer {
     const orc_scene &S;
@@ -441,8 +443,12 @@ struct Tracer {
                 const int sl = slot_at[k];
                 float tmin = 0, tmax = 0;
                 for (int a = 0; a < 3; ++a) {
-                    const float lo = fmaf((float)((qlo[a] >> (8 * sl)) & 255u), scale[a], f[a]);
-                    const float hi = fmaf((float)((qhi[a] >> (8 * sl)) & 255u), scale[a], f[a]);
+                    float lo = fmaf((float)((qlo[a] >> (8 * sl)) & 255u), scale[a], f[a]);
+                    float hi = fmaf((float)((qhi[a] >> (8 * sl)) & 255u), scale[a], f[a]);
+                    if (g_walk_exact_slots && !S.wide_slot_node.empty() && S.wide_slot_node[(size_t)cur * 4 + sl] >= 0) {
+                        lo = S.nodes[(size_t)S.wide_slot_node[(size_t)cur * 4 + sl]].bmin[a];
+                        hi = S.nodes[(size_t)S.wide_slot_node[(size_t)cur * 4 + sl]].bmax[a];
+                    }
                     const float t_in = ((neg[a] ? hi : lo) - oo[a]) * ii[a], t_out = ((neg[a] ? lo : hi) - oo[a]) * ii[a];
                     // fmaxf / fminf: of a number and a NaN the number, as the device's max3 / min3
                     tmin = a == 0 ? t_in : fmaxf(tmin, t_in);
@@ -1564,6 +1570,7 @@ int orc_intersect_wide(orc_scene *s, const float *o, const float *d, float time,
 // 1: orc_render / orc_trace_primary walk the wide tree of scenes whose wide tree has been built (orc_intersect_wide
 // builds it); counters then count the root box only.  For checking that both walks give the same image.
 void orc_set_wide(int on) { g_walk_wide = on; }
+void orc_set_exact_slots(int on) { g_walk_exact_slots = on; }
 long orc_walk_mismatches(void) { return g_walk_mismatches.load(); }
 // work of the walks on the calling thread since the last call (render with one thread): wide steps, leaves reached by
 // the wide walk, pushes, deepest stack, interior nodes expanded by the two-child walk, leaves whose exact box passed
@@ -1603,6 +1610,8 @@ long orc_wide_check(orc_scene *s, long *n_records) {
         const rt_bvh_node *N = s->nodes.data();
         const int L = node + 1, R = N[node].offset;
         int slot[4] = {N[L].n_prims ? L : L + 1, N[L].n_prims ? -1 : N[L].offset, N[R].n_prims ? R : R + 1, N[R].n_prims ? -1 : N[R].offset};
+        if (s->wide_slot_node.size() != s->wide.size() * 4) s->wide_slot_node.assign(s->wide.size() * 4, -1);
+        for (int k = 0; k < 4; ++k) s->wide_slot_node[(size_t)rec * 4 + k] = slot[k];
         unsigned w[16];
         const float *f = s->wide[(size_t)rec].f;
         memcpy(w, f, sizeof w);

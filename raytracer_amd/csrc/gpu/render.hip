@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_
         if (prim <= -2) {
             shape = S.n_triangles + S.n_spheres + (-2 - prim);
         } else if (prim >= 0) {
-            const int4 meta = S.prim_meta[(size_t)prim];
+            const int4 meta = S.prim_meta[2 * (size_t)prim];
             shape = meta.y;
             id = meta.z;
         }
@@ -1589,7 +1589,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
-    std::vector<int4> prim_meta((size_t)d->n_bvh_prims);
+    std::vector<int4> prim_meta((size_t)d->n_bvh_prims * 2, make_int4(0, 0, 0, 0));
     auto as_float = [](int v) {
         float f;
         memcpy(&f, &v, 4);
@@ -1609,13 +1609,13 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             prims[PRIM_STRIDE * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
             const rt_instance &in = d->instances[p.instance];
             const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
-            prim_meta[i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(prim_meta[i].x), 0.f, 0.f);
+            prim_meta[2 * (size_t)i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, t.smooth ? 1 : 0);
+            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(prim_meta[2 * (size_t)i].x), 0.f, 0.f);
         } else {
             prims[PRIM_STRIDE * i] = make_float4(0, 0, 0, 0);
             prims[PRIM_STRIDE * i + 1] = make_float4(0, 0, 0, 0);
-            prim_meta[i] = make_int4(-1 - (p.shape - d->n_triangles), p.shape, 123456, 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(prim_meta[i].x), 0.f, 0.f);
+            prim_meta[2 * (size_t)i] = make_int4(-1 - (p.shape - d->n_triangles), p.shape, 123456, 0);
+            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(prim_meta[2 * (size_t)i].x), 0.f, 0.f);
         }
         prims[PRIM_STRIDE * i + 3] = make_float4(0, 0, 0, 0);
     }
@@ -1650,6 +1650,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         for (int a = 0; a < 3; ++a) flat[3 * i + a] = len2 > 1e-12f ? n[a] * inv : 0.0f;
     }
 
+    for (int i = 0; i < d->n_bvh_prims; ++i) {   // the face normal travels with the entry's shading record
+        const rt_bvh_prim &p = d->bvh_prims[i];
+        if (p.shape >= d->n_triangles) continue;
+        int bits[3];
+        memcpy(bits, &flat[3 * (size_t)p.shape], sizeof bits);
+        prim_meta[2 * (size_t)i + 1] = make_int4(bits[0], bits[1], bits[2], 0);
+    }
+
 #define UP(field, vec_ptr, count)                                                     \
     do {                                                                              \
         decltype(D.field) dp_ = nullptr;                                              \
@@ -1669,7 +1677,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     UP(inst, inst.data(), inst.size());
     UP(instances, d->instances, d->n_instances);
     UP(triangles, d->triangles, d->n_triangles);
-    UP(flat_normals, flat.data(), flat.size());
     UP(spheres, d->spheres, d->n_spheres);
     UP(planes, d->planes, d->n_planes);
     UP(materials, d->materials, d->n_materials);

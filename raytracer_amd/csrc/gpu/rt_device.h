@@ -26,7 +26,8 @@ enum {
 //         entry belongs to, so that the wide walk's exact leaf test and the first entry's test read the same block:
 //         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), leaf min.xy} {leaf min.z, leaf max.xyz}
 //         sphere   {...unused...}                 {0, bits(-1 - sphere), leaf min.xy} {leaf min.z, leaf max.xyz}
-// prim_meta: per leaf entry {bits(instance) as above, shape, reference id, 0}: what shading needs of a hit entry
+// prim_meta: 2 x int4 per leaf entry: what shading needs of a hit entry, in one 32-byte block:
+//         {bits(instance) as above, shape, reference id, smooth shading?} {flat normal.xyz, 0}
 // inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
 //         flags bit0 = identity transform, bit1 = has motion blur
 // wnodes: 4 x float4 per WIDE node: an interior node merged with those of its two children that are interior, so
@@ -43,7 +44,6 @@ struct DevScene {
     const float4 *inst;
     const rt_instance *instances;
     const rt_triangle *triangles;
-    const float *flat_normals;
     const rt_sphere *spheres;
     const rt_plane *planes;
     const rt_material *materials;
@@ -436,6 +436,8 @@ struct Surface {
     int instance;   // placement (triangles)
     int material;
     int toff, tcount;
+    bool smooth;    // triangles: interpolated vertex normals
+    V flat;         // triangles: the face normal in object space
 };
 
 __device__ Surface surface_of(const DevScene &S, const Hit &h) {
@@ -450,7 +452,9 @@ __device__ Surface surface_of(const DevScene &S, const Hit &h) {
         s.tcount = p.tex_count;
         return s;
     }
-    const int4 meta = S.prim_meta[(size_t)h.prim];
+    const int4 meta = S.prim_meta[2 * (size_t)h.prim], meta1 = S.prim_meta[2 * (size_t)h.prim + 1];
+    s.smooth = meta.w != 0;
+    s.flat = mk(__int_as_float(meta1.x), __int_as_float(meta1.y), __int_as_float(meta1.z));
     int inst = meta.x;
     if (inst >= 0) {
         inst &= ~PRIM_XFORM_BIT;
@@ -476,9 +480,9 @@ __device__ Surface surface_of(const DevScene &S, const Hit &h) {
 // get_normal: triangle src/shapes.cpp:152-197, sphere :390-405, plane :504
 __device__ V normal_of(const DevScene &S, const Surface &s, V p) {
     if (s.kind == 0) {
-        const rt_triangle &t = S.triangles[s.index];
         const rt_instance &in = S.instances[s.instance];
-        if (!t.smooth) return normalize(xdir(in.normal, mk(S.flat_normals + 3 * s.index)));
+        if (!s.smooth) return normalize(xdir(in.normal, s.flat));
+        const rt_triangle &t = S.triangles[s.index];
         V po = xpoint(in.inv_model, p);
         V c1 = mk(t.c1);
         V v0 = sub(mk(t.c2), c1), v1 = sub(mk(t.c3), c1), v2 = sub(po, c1);

@@ -28,13 +28,15 @@ def main():
         assert o.wide_check()[0] == 0
         w = (C.c_long * 6)()
         L.orc_walk_work(w)
-        for mode in (0, 1):
-            L.orc_set_wide(mode)
+        for mode in (0, 1, 2):   # 2: the wide walk with the slots' exact boxes -- what the 8-bit grid costs in steps
+            L.orc_set_exact_slots(1 if mode == 2 else 0)
+            L.orc_set_wide(min(mode, 1))
             _, st = o.render(cam, threads=1)
             L.orc_set_wide(0)
             L.orc_walk_work(w)
             rays = st.primary_rays + st.shadow_rays + st.secondary_rays
-            print(("two-child walk" if mode == 0 else "wide walk     "), f"{rays} rays; per ray: interior nodes expanded {w[4] / rays:.2f}, wide steps {w[0] / rays:.2f}, "
+            L.orc_set_exact_slots(0)
+            print(("two-child walk", "wide walk     ", "wide, exact   ")[mode], f"{rays} rays; per ray: interior nodes expanded {w[4] / rays:.2f}, wide steps {w[0] / rays:.2f}, "
                   f"leaves reached {w[1] / rays:.2f}, leaves whose exact box passed {w[5] / rays:.2f}, pushes {w[2] / rays:.2f}, "
                   f"deepest stack {w[3]}, triangle tests {st.triangle_tests / rays:.2f}")
     else:
