@@ -286,7 +286,11 @@ int rt_trace_primary(rt_scene *scene, const rt_camera_desc *cam, int32_t *shape_
 int rt_set_profiling(rt_scene *scene, int32_t enabled);
 int rt_kernel_times(const rt_scene *scene, rt_kernel_time *out);
 
-/* Enables per-ray traversal counters (nodes visited, primitive tests) in subsequent renders. */
+/* Enables per-ray traversal counters (nodes visited, primitive tests) in subsequent renders.  Counted renders walk the
+ * BVH node by node as bvh::intersect does (src/bvh.cpp:383-480), so the counts are the reference's; renders without
+ * counters may walk a wide form of the same tree (four quantised boxes per record, leaves filtered by their exact box)
+ * that tests the same primitives in the same order and returns the same hits.  No reference counterpart (the reference
+ * does not count). */
 int rt_set_counters(rt_scene *scene, int32_t enabled);
 
 void rt_scene_destroy(rt_scene *scene);
