@@ -40,15 +40,15 @@ def test_wide_walk_equals_two_box_walk(name, scene_dir, monkeypatch):
 
 
 def test_the_switch_to_the_wide_tree_is_invisible(scene_dir, monkeypatch):
-    """By default a scene gets its wide tree once it has been asked for 64 camera paths per BVH node (building it costs
-    host time that few rays do not repay): the 70 K-triangle scene changes walks with its fourth 1080p frame.  The
+    """By default a scene gets its wide tree once it has been asked for 256 camera paths per BVH node (building it costs
+    host time that few rays do not repay): the 70 K-triangle scene changes walks with its sixteenth 1080p frame.  The
     frames before and after are the same."""
     monkeypatch.delenv("RT_WIDE_NODES", raising=False)
     sc = R.Scene(path_of("mesh70k", scene_dir))
-    assert 3 * 1920 * 1080 < 64 * sc.desc.n_bvh_nodes < 4 * 1920 * 1080      # the fourth frame is the first on the wide tree
+    assert 15 * 1920 * 1080 < 256 * sc.desc.n_bvh_nodes < 16 * 1920 * 1080      # the sixteenth frame is the first on the wide tree
     cam = sc.camera(0)
     ren = R.Renderer(sc)
-    frames = [ren.render(cam)[0] for _ in range(7)]
+    frames = [ren.render(cam)[0] for _ in range(18)]
     for f in frames[1:]:
         assert np.abs(f - frames[0]).max() <= 1e-5 * max(1.0, float(frames[0].max()))
     ids = [ren.trace_primary(cam) for _ in range(2)]
