@@ -229,10 +229,13 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
 // iteration the wave votes on what to run:
 //   refill   when at least REFILL_MIN lanes have no ray, they claim the next queue entries with one atomic
 //   pop      lanes whose node is finished take the next one from their stack (or finish the ray)
-//   node     lanes at an interior node test both child boxes -- unless enough lanes wait at a leaf
+//   node     lanes at an interior node test its child boxes
 //   leaf     lanes at a leaf test one primitive each -- once LEAF_MIN lanes wait, or more lanes wait than walk
 // Incoherent rays leave a wave's lanes at different places in the tree; running the long leaf code for one lane
-// while 63 wait (and the reverse) is what the vote avoids.  Each lane still executes exactly the sequential
+// while 63 wait is what the vote avoids.  The node step runs in every iteration that has a lane for it, and the leaf
+// step follows in the same iteration when its vote passes (lanes that reached a leaf in that node step
+// included): no lane sits out an iteration because the other kind of step was chosen (closest-hit time -2 %).
+// -DRT_SEPARATE_STEPS: one kind of step per iteration.  Each lane still executes exactly the sequential
 // algorithm for its ray, so results and counters do not depend on the schedule.
 struct TraceTuning {
     int refill_min;   // idle lanes that trigger a refill
@@ -361,7 +364,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) ++pf_node_it, pf_node_ln += n_node;
         else if (n_leaf) ++pf_leaf_it, pf_leaf_ln += n_leaf;
 #endif
-        if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) {
+#ifndef RT_SEPARATE_STEPS
+        const bool run_node = n_node != 0;
+#else
+        const bool run_node = n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node);
+#endif
+        if (run_node) {
             if ((unsigned)r.cur < (unsigned)REF_POP) {
                 if (WIDE) {
                     wide_step(S, r, lds, spill, top_nodes, n_top);
@@ -375,7 +383,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 } else
                     node_step<COUNT>(S, r, lds, spill, top_nodes, n_top, c);
             }
-        } else if (n_leaf) {
+        }
+#ifndef RT_SEPARATE_STEPS
+        // after the node step: lanes that have just reached a leaf count, and take part
+        const int n_leaf_now = __popcll(__ballot(r.cur < 0)), n_node_now = __popcll(__ballot((unsigned)r.cur < (unsigned)REF_POP));
+        const bool run_leaf = n_leaf_now && (n_leaf_now >= tune.leaf_min || n_leaf_now >= n_node_now);
+#else
+        const bool run_leaf = !run_node && n_leaf;
+#endif
+        if (run_leaf) {
             if (r.cur < 0) {
                 const int k = r.cur & 0xffffff;
                 const float4 *entry = S.prims + PRIM_STRIDE * (size_t)k;   // one 64-byte block, read at once
