@@ -360,10 +360,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         const unsigned long long at_node = __ballot((unsigned)r.cur < (unsigned)REF_POP);
         const unsigned long long at_leaf = __ballot(r.cur < 0);
         const int n_node = __popcll(at_node), n_leaf = __popcll(at_leaf);
-#ifdef RT_TRACE_PROFILE
-        if (n_node && !(n_leaf >= tune.leaf_min || n_leaf >= n_node)) ++pf_node_it, pf_node_ln += n_node;
-        else if (n_leaf) ++pf_leaf_it, pf_leaf_ln += n_leaf;
-#endif
 #ifndef RT_SEPARATE_STEPS
         const bool run_node = n_node != 0;
 #else
@@ -390,6 +386,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         const bool run_leaf = n_leaf_now && (n_leaf_now >= tune.leaf_min || n_leaf_now >= n_node_now);
 #else
         const bool run_leaf = !run_node && n_leaf;
+#endif
+#ifdef RT_TRACE_PROFILE
+        if (run_node) ++pf_node_it, pf_node_ln += n_node;
+        if (run_leaf) ++pf_leaf_it, pf_leaf_ln += __popcll(__ballot(r.cur < 0));
 #endif
         if (run_leaf) {
             if (r.cur < 0) {
