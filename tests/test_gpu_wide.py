@@ -55,3 +55,22 @@ def test_the_switch_to_the_wide_tree_is_invisible(scene_dir, monkeypatch):
     ren.set_counters(True)
     shape_2, id_2, t_2, _ = ren.trace_primary(cam)
     assert np.array_equal(ids[1][0], shape_2) and np.array_equal(ids[1][2].view(np.uint32), t_2.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["materials", "transforms", "mesh70k"])
+def test_rays_parallel_to_an_axis(name, scene_dir, monkeypatch):
+    """An odd image width puts a column of pixels on the camera's vertical plane: those rays have a direction component
+    that is exactly zero, so one reciprocal is infinite and slab products are +-inf (or NaN on a box face).  Both GPU
+    walks and the CPU oracle must agree on them too."""
+    from oracle_lib import Oracle
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    sc = R.Scene(path_of(name, scene_dir))
+    cam = sc.camera(0, resx=97, resy=65)
+    ren = R.Renderer(sc)
+    shape_w, id_w, t_w, _ = ren.trace_primary(cam)
+    ren.set_counters(True)
+    shape_2, id_2, t_2, _ = ren.trace_primary(cam)
+    shape_o, id_o, t_o, _ = Oracle(sc).trace_primary(cam)
+    assert np.array_equal(shape_w, shape_2) and np.array_equal(t_w.view(np.uint32), t_2.view(np.uint32))
+    assert np.array_equal(shape_w, shape_o) and np.array_equal(id_w, id_o) and np.array_equal(t_w.view(np.uint32), t_o.view(np.uint32))
+    assert (shape_w.reshape(65, 97)[:, 48] >= 0).any()       # the centre column sees the scene
