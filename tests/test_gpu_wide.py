@@ -74,3 +74,19 @@ def test_rays_parallel_to_an_axis(name, scene_dir, monkeypatch):
     assert np.array_equal(shape_w, shape_2) and np.array_equal(t_w.view(np.uint32), t_2.view(np.uint32))
     assert np.array_equal(shape_w, shape_o) and np.array_equal(id_w, id_o) and np.array_equal(t_w.view(np.uint32), t_o.view(np.uint32))
     assert (shape_w.reshape(65, 97)[:, 48] >= 0).any()       # the centre column sees the scene
+
+
+def test_full_size_frame_same_on_both_walks(scene_dir, monkeypatch):
+    """The benchmark scene at its full resolution (3840x2160, 1M triangles; 16 of its 256 samples per pixel): the wide
+    walk's image against the two-box walk's, whose visits are the reference's."""
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    sc = R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt1m_4k", width=3840, height=2160, spp=16))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    img_w, st_w = ren.render(cam)
+    ren.set_counters(True)
+    img_2, st_2 = ren.render(cam)
+    assert st_w.nodes_visited == 0 and st_2.nodes_visited > 30 * st_2.total_rays // 2
+    assert (st_w.primary_rays, st_w.secondary_rays) == (st_2.primary_rays, st_2.secondary_rays) and st_w.primary_rays == 3840 * 2160 * 16
+    err = np.abs(img_w - img_2) / np.maximum(np.abs(img_2), 1 / 255)
+    assert err.max() <= 1e-5
