@@ -31,6 +31,8 @@ WORKLOADS = {
     # config 4: 1M+ triangle mesh, path traced, 4K, 256 spp
     "pt1m_4k_256spp": dict(kind="pt", n=710, width=3840, height=2160, spp=256, max_depth=4,
                            cpu=dict(width=480, height=270, spp=16)),
+    # config 3: textured multi-object scene, two area lights, glossy mirror, depth of field, 64 spp (Whitted shading)
+    "textured_1080p_64spp": dict(kind="textured", n=188, width=1920, height=1080, spp=64, cpu=dict(width=480, height=270, spp=16)),
     # config 2: ~70K triangle mesh, Blinn-Phong + shadows, 1080p, 1 spp
     "mesh70k_1080p": dict(kind="mesh", n=188, width=1920, height=1080, cpu=dict(width=1920, height=1080)),
 }
@@ -43,6 +45,8 @@ def make_scene(scenegen, out_dir, w, name, cpu=False):
     if w["kind"] == "pt":
         return scenegen.write_path_traced_scene(out_dir, name=name, n=w["n"], width=dims["width"], height=dims["height"],
                                                 spp=dims["spp"], max_depth=w["max_depth"])
+    if w["kind"] == "textured":
+        return scenegen.write_textured_scene(out_dir, name=name, n=w["n"], width=dims["width"], height=dims["height"], spp=dims["spp"])
     return scenegen.write_mesh_scene(out_dir, name=name, n=w["n"], width=dims["width"], height=dims["height"])
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.npz from the compiled reference (oracle/_ref/ref_dump).
 
-Run in the CPU container where /root/reference is present:  python tests/golden/make_golden.py
+Run in the CPU container where /root/reference is present:  python tests/golden/make_golden.py [scene names]
+(no names: every scene).
 For every scene the reference's own parser, BVH and integrators produce
   ids   (H*W, 2) int32   primary-hit (shape index, instance id), -1/-1 on a miss   [1-spp scenes]
   t     (H*W,)   float32 primary-hit distance, 1e30 on a miss                      [1-spp scenes]
@@ -53,7 +54,10 @@ def main():
         jobs = [(name, builder(os.path.join(tmp, "scenes")), kind) for name, (builder, kind) in S.SCENES.items()]
         jobs.append(("simple", os.path.join(ROOT, "scenes", "simple.json"), "exact"))
         jobs.append(("mesh70k", scenegen.write_mesh_scene(os.path.join(tmp, "scenes"), name="mesh70k", n=188, width=320, height=180), "exact"))
+        only = set(sys.argv[1:])
         for name, path, kind in jobs:
+            if only and name not in only:
+                continue
             prefix = os.path.join(tmp, name)
             if kind == "exact":
                 ids, t, hdr, bvh = run_ref(path, prefix)

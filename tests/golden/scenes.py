@@ -387,6 +387,65 @@ def pathtrace_env_scene(out_dir):
     return dump(out_dir, "pt_env", sc)
 
 
+def env_probe_scene(out_dir):
+    """Angular-probe environment map (get_probe_uv, src/ray_trace.cpp:24-39) as background and cosine-sampled light."""
+    os.makedirs(out_dir, exist_ok=True)
+    write_exr(os.path.join(out_dir, "probe.exr"), sky_image(48, 48))
+    mats = [MAT_DIFFUSE, {"_id": "2", "_type": "mirror", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0 0 0",
+                          "SpecularReflectance": "0 0 0", "MirrorReflectance": "0.95 0.95 0.95"}]
+    verts = GROUND + "  0 0.7 0"
+    objects = {"Mesh": {"_id": "1", "Material": "1", "Faces": {"_data": GROUND_FACES}},
+               "Sphere": {"_id": "1", "Material": "2", "Center": "5", "Radius": "0.7"}}
+    lights = {"AmbientLight": "0 0 0", "SphericalDirectionalLight": {"_id": "1", "_type": "probe", "ImageId": "1", "Sampler": "cosine"}}
+    sc = scene(camera("env_probe.exr", res=(96, 64), NumSamples="16"), lights, mats, verts, objects)
+    sc["Scene"]["Textures"] = {"Images": {"Image": {"_id": "1", "_data": "probe.exr"}}}
+    return dump(out_dir, "env_probe", sc)
+
+
+def env_uniform_scene(out_dir):
+    """Lat-long environment light sampled uniformly over the hemisphere (the else-branch of
+    SphericalDirectionalLight::get_sample, src/lights.cpp:235)."""
+    os.makedirs(out_dir, exist_ok=True)
+    write_exr(os.path.join(out_dir, "sky.exr"), sky_image())
+    mats = [MAT_DIFFUSE, {"_id": "2", "AmbientReflectance": "1 1 1", "DiffuseReflectance": "0.3 0.5 0.8", "SpecularReflectance": "0.4 0.4 0.4",
+                          "PhongExponent": "15"}]
+    verts = GROUND + "  -0.7 0.6 0  0.9 0.45 0.6"
+    objects = {"Mesh": {"_id": "1", "Material": "1", "Faces": {"_data": GROUND_FACES}},
+               "Sphere": [{"_id": "1", "Material": "2", "Center": "5", "Radius": "0.6"},
+                          {"_id": "2", "Material": "1", "Center": "6", "Radius": "0.45"}]}
+    lights = {"AmbientLight": "0 0 0", "SphericalDirectionalLight": {"_id": "1", "_type": "latlong", "ImageId": "1", "Sampler": "uniform"}}
+    sc = scene(camera("env_uniform.exr", res=(96, 64), NumSamples="16"), lights, mats, verts, objects)
+    sc["Scene"]["Textures"] = {"Images": {"Image": {"_id": "1", "_data": "sky.exr"}}}
+    return dump(out_dir, "env_uniform", sc)
+
+
+def background_scene(out_dir):
+    """An 8-bit background image (DecalMode replace_background) looked up by pixel position for every ray that leaves
+    the scene, reflected ones included (src/main.cpp:380-388,455-456, src/ray_trace.cpp:691-721), and a mesh whose
+    face indices are shifted by _vertexOffset (src/parser.cpp:749-752)."""
+    os.makedirs(out_dir, exist_ok=True)
+    write_png(os.path.join(out_dir, "backdrop.png"), checker_image(48, 6))
+    mats = [MAT_DIFFUSE, {"_id": "2", "_type": "mirror", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0.05 0.05 0.05",
+                          "SpecularReflectance": "0.1 0.1 0.1", "MirrorReflectance": "0.9 0.9 0.9"},
+            {"_id": "3", "AmbientReflectance": "1 1 1", "DiffuseReflectance": "0.8 0.5 0.2", "SpecularReflectance": "0.2 0.2 0.2", "PhongExponent": "12"}]
+    verts = "-2.5 0 -2.5  2.5 0 -2.5  2.5 0 2.5  -2.5 0 2.5  " + verts_str([(x - 1.9, y, z - 0.3) for x, y, z in CUBE_V]) + "  0.6 0.7 0.2"
+    objects = {"Mesh": [{"_id": "1", "Material": "1", "Faces": {"_data": GROUND_FACES}},
+                        {"_id": "2", "Material": "3", "Faces": {"_data": faces_str(CUBE_F, 0), "_vertexOffset": "4"}}],
+               "Sphere": {"_id": "1", "Material": "2", "Center": "13", "Radius": "0.7"}}
+    sc = scene(camera("background.png", res=(112, 80)), TWO_LIGHTS, mats, verts, objects)
+    sc["Scene"]["Textures"] = {"Images": {"Image": {"_id": "1", "_data": "backdrop.png"}},
+                               "TextureMap": {"_id": "1", "_type": "image", "ImageId": "1", "DecalMode": "replace_background",
+                                              "Interpolation": "bilinear"}}
+    return dump(out_dir, "background", sc)
+
+
+def textured_scene(out_dir):
+    """The benchmark's textured scene with distribution effects in small: checkerboard ground, Perlin mesh, image-mapped
+    wall and sphere, glossy mirror (roughness 0.1), two area lights, depth of field, 64 samples per pixel."""
+    from raytracer_amd import scenegen
+    return scenegen.write_textured_scene(out_dir, name="textured", n=24, width=96, height=72, spp=64)
+
+
 SCENES = {
     "materials": (materials_scene, "exact"),
     "textures": (textures_scene, "exact"),
@@ -398,4 +457,8 @@ SCENES = {
     "pt_uniform": (pathtrace_uniform_scene, "stochastic"),
     "emitters": (emitters_scene, "stochastic"),
     "pt_env": (pathtrace_env_scene, "stochastic"),
+    "env_probe": (env_probe_scene, "stochastic"),
+    "env_uniform": (env_uniform_scene, "stochastic"),
+    "background": (background_scene, "exact"),
+    "textured": (textured_scene, "stochastic"),
 }
