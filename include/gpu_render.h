@@ -313,6 +313,16 @@ typedef struct rt_tonemap_desc {
 } rt_tonemap_desc;
 int rt_tonemap(const float *hdr, int32_t width, int32_t height, const rt_tonemap_desc *tm, uint8_t *rgb8_out);
 
+/* rt_tonemap for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc):
+ * no counterpart in the reference.  The same kernels and the same result, byte for byte, as rt_tonemap; what rt_tonemap
+ * allocates per call lives in a fixed array of device memory inside the library instead (9.3 KB per GPU: the partial
+ * sums of the log-average, the state and histogram of the white-point selection), and the luminance plane is not kept
+ * but re-evaluated.  hdr and rgb8_out must both be device memory on the current device; at most
+ * RT_TONEMAP_NOALLOC_MAX_PIXELS pixels (error 5 beyond).  The call allocates and frees nothing, synchronises the device
+ * before it returns, and every call on a GPU uses that GPU's one array: calls that overlap on the same GPU race. */
+#define RT_TONEMAP_NOALLOC_MAX_PIXELS (1 << 28)
+int rt_tonemap_noalloc(const float *hdr, int32_t width, int32_t height, const rt_tonemap_desc *tm, uint8_t *rgb8_out);
+
 /* The reference's plain LDR conversion, (unsigned char)clamp(v * 255, 0, 255) (src/main.cpp:579-583), on the device. */
 int rt_quantize_ldr(const float *hdr, int64_t n_values, uint8_t *out);
 

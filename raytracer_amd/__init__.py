@@ -73,6 +73,7 @@ def gpu_lib():
         g.rt_shard_owner_map.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         g.rt_set_counters.argtypes = [C.c_void_p, C.c_int32]
         g.rt_tonemap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(A.TonemapDesc), C.c_void_p]
+        g.rt_tonemap_noalloc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(A.TonemapDesc), C.c_void_p]
         g.rt_quantize_ldr.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         g.rt_set_profiling.argtypes = [C.c_void_p, C.c_int32]
         g.rt_kernel_times.argtypes = [C.c_void_p, C.POINTER(A.KernelTime)]

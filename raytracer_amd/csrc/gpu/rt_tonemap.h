@@ -14,14 +14,15 @@ constexpr int TM_BLOCKS = 1024;
 
 __device__ __forceinline__ float tm_luminance(const float *p) { return 0.2126f * p[0] + 0.7152f * p[1] + 0.0722f * p[2]; }
 
-// lum[i] and one double partial sum of log(1e-4 + max(lum, 0)) per block
+// lum[i] and one double partial sum of log(1e-4 + max(lum, 0)) per block.  With `lum` null no luminance plane is kept:
+// the later kernels then evaluate tm_luminance again from `hdr` (the same instructions, so the same bits).
 __global__ void __launch_bounds__(TM_THREADS) tm_luminance_kernel(const float *__restrict__ hdr, size_t n, float *__restrict__ lum,
                                                                    double *__restrict__ partial) {
     __shared__ double sums[TM_THREADS];
     double acc = 0.0;
     for (size_t i = (size_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * TM_THREADS) {
         const float l = tm_luminance(hdr + 3 * i);
-        lum[i] = l;
+        if (lum) lum[i] = l;
         acc += (double)logf(1e-4f + (l < 0.0f ? 0.0f : l));
     }
     sums[threadIdx.x] = acc;
@@ -34,7 +35,7 @@ __global__ void __launch_bounds__(TM_THREADS) tm_luminance_kernel(const float *_
 }
 
 // state[0] = bit-pattern prefix found so far, state[1] = rank still to find inside it, state[2] = result bits
-__global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *__restrict__ lum, size_t n, float exposure, int pass,
+__global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *__restrict__ hdr, const float *__restrict__ lum, size_t n, float exposure, int pass,
                                                                    const unsigned *__restrict__ state, unsigned *__restrict__ hist) {
     __shared__ unsigned local[256];
     local[threadIdx.x] = 0;
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *_
     const unsigned prefix = state[0];
     const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
     for (size_t i = (size_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * TM_THREADS) {
-        const float l = lum[i];
+        const float l = lum ? lum[i] : tm_luminance(hdr + 3 * i);
         const unsigned bits = __float_as_uint((l < 0.0f ? 0.0f : l) * exposure);   // non-negative: bit order = value order
         if ((bits & mask) == prefix) atomicAdd(&local[(bits >> shift) & 255u], 1u);
     }
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(TM_THREADS) tm_apply_kernel(const float *__res
     if (p.tmo == RT_TMO_ACES) denom = fmaxf(tm_aces(white), 1e-6f);
     if (p.tmo == RT_TMO_FILMIC) denom = fmaxf(tm_filmic(white), 1e-6f);
     for (size_t i = (size_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * TM_THREADS) {
-        const float y_in = lum[i];
+        const float y_in = lum ? lum[i] : tm_luminance(hdr + 3 * i);
         const float L = (y_in < 0.0f ? 0.0f : y_in) * p.exposure;
         float y_out = 0.0f;
         if (p.tmo == RT_TMO_PHOTOGRAPHIC)
@@ -144,6 +145,41 @@ struct TmBuffers {
         return p;
     }
 };
+
+// ---- scratch of rt_tonemap_noalloc ------------------------------------------------------------------------------
+// Everything rt_tonemap allocates per call except the luminance plane (which the no-allocation variant does without):
+// TM_BLOCKS double partial sums, then the radix select's state (4 words) and histogram (256 words).  One copy per GPU
+// for the life of the process; calls that overlap on one GPU would race on it.
+constexpr size_t TM_SCRATCH_PARTIAL_BYTES = TM_BLOCKS * sizeof(double);
+constexpr size_t TM_SCRATCH_BYTES = TM_SCRATCH_PARTIAL_BYTES + (4 + 256) * sizeof(unsigned);
+static __device__ __align__(256) unsigned char scratch[(TM_SCRATCH_BYTES + 255) / 256 * 256];
+
+// The device address of `scratch` on the current device.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; every GPU holds its own copy at its own address, looked up once per device.
+constexpr int TM_MAX_DEVICES = 64;
+std::mutex g_tm_scratch_mutex;
+void *g_tm_scratch_ptr[TM_MAX_DEVICES] = {};
+
+int tm_scratch_of_current_device(void **out) {
+    int dev = -1;
+    HIP_OK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= TM_MAX_DEVICES) {
+        g_error = "rt_tonemap_noalloc: device index out of range";
+        return 10;
+    }
+    std::lock_guard<std::mutex> lk(g_tm_scratch_mutex);
+    if (!g_tm_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        HIP_OK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) {
+            g_error = "rt_tonemap_noalloc: no device address for the scratch array";
+            return 10;
+        }
+        g_tm_scratch_ptr[dev] = ptr;
+    }
+    *out = g_tm_scratch_ptr[dev];
+    return 0;
+}
 
 }  // namespace
 
@@ -197,13 +233,65 @@ int rt_tonemap(const float *hdr, int32_t width, int32_t height, const rt_tonemap
         HIP_OK(hipMemcpy(state, init, sizeof init, hipMemcpyHostToDevice));
         HIP_OK(hipMemset(hist, 0, 256 * sizeof(unsigned)));
         for (int pass = 0; pass < 4; ++pass) {
-            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, lum, n, p.exposure, pass, state, hist);
+            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, lum, n, p.exposure, pass, state, hist);
             hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1), 0, 0, pass, state, hist);
         }
     }
     hipLaunchKernelGGL(tm_apply_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, lum, n, p, state, d_out);
     HIP_OK(hipGetLastError());
     if (!out_dev) HIP_OK(hipMemcpy(rgb8_out, d_out, n * 3, hipMemcpyDeviceToHost));
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}
+
+int rt_tonemap_noalloc(const float *hdr, int32_t width, int32_t height, const rt_tonemap_desc *tm, uint8_t *rgb8_out) {
+    if (!hdr || !tm || !rgb8_out || width < 1 || height < 1 || tm->tmo < RT_TMO_PHOTOGRAPHIC || tm->tmo > RT_TMO_ACES) {
+        g_error = "rt_tonemap_noalloc: bad argument";
+        return 1;
+    }
+    if ((int64_t)width * height > RT_TONEMAP_NOALLOC_MAX_PIXELS) {
+        g_error = "rt_tonemap_noalloc: frame larger than RT_TONEMAP_NOALLOC_MAX_PIXELS (2^28 pixels: ranks and histogram counts in the scratch buffer are 32-bit)";
+        return 5;
+    }
+    if (!tm_on_device(hdr) || !tm_on_device(rgb8_out)) {
+        g_error = "rt_tonemap_noalloc: hdr and rgb8_out must be device memory (staging host buffers would need an allocation)";
+        return 1;
+    }
+    void *base = nullptr;
+    if (int rc = tm_scratch_of_current_device(&base)) return rc;
+    double *partial = (double *)base;
+    unsigned *state = (unsigned *)((unsigned char *)base + TM_SCRATCH_PARTIAL_BYTES), *hist = state + 4;
+    const size_t n = (size_t)width * height;
+    const int blocks = (int)std::min<size_t>(TM_BLOCKS, (n + TM_THREADS - 1) / TM_THREADS);
+    // the array keeps the previous call's contents: every block of this launch overwrites its partial sum, and the
+    // select state and histogram are set below before they are read
+    hipLaunchKernelGGL(tm_luminance_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, n, (float *)nullptr, partial);
+    HIP_OK(hipGetLastError());
+    double host_partial[TM_BLOCKS];
+    HIP_OK(hipMemcpy(host_partial, partial, blocks * sizeof(double), hipMemcpyDeviceToHost));
+    double sum_log = 0.0;
+    for (int b = 0; b < blocks; ++b) sum_log += host_partial[b];
+    const float avg = (float)std::exp(sum_log / (double)n);
+    TonemapParams p;
+    p.tmo = tm->tmo;
+    p.exposure = avg > 1e-6f ? tm->opt1 / avg : 1.0f;
+    p.saturation = tm->saturation + 0.2f;
+    p.inv_gamma = 1.0f / (tm->gamma > 1e-6f ? tm->gamma : 2.2f);
+    p.use_state_white = tm->opt2 > 1e-6f ? 1 : 0;
+    if (p.use_state_white) {
+        const float pct = (100.0f - tm->opt2) / 100.0f;
+        long long k = (long long)std::floor(pct * (float)(n - 1));
+        k = std::max<long long>(0, std::min<long long>((long long)n - 1, k));
+        const unsigned init[4] = {0u, (unsigned)k, 0u, 0u};
+        HIP_OK(hipMemcpy(state, init, sizeof init, hipMemcpyHostToDevice));
+        HIP_OK(hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), 0));
+        for (int pass = 0; pass < 4; ++pass) {
+            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, (const float *)nullptr, n, p.exposure, pass, state, hist);
+            hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1), 0, 0, pass, state, hist);
+        }
+    }
+    hipLaunchKernelGGL(tm_apply_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, (const float *)nullptr, n, p, state, rgb8_out);
+    HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
     return 0;
 }
