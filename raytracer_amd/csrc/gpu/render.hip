@@ -475,12 +475,12 @@ __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard,
 // Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
 template <bool PT>
 // waves per SIMD the register allocation aims at, measured (4K / 64 spp frame): shade 3: 86 ms, 4: 81, 5: 106 (spills);
-// gather 3: 95 ms, 6: 90, 7: 103
+// gather (two emitter samples per round, packed) 4: 58.5 ms, 5: 61.8, 6: 64.5, 8: 67.7
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
 #ifndef RT_GATHER_WAVES
-#define RT_GATHER_WAVES 6
+#define RT_GATHER_WAVES 4
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
@@ -979,24 +979,48 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
                 lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3]) + rec_lane] != 0.f;
             }
             if (__ballot(lit) == 0) continue;
+            // what every lane needs of the emitter, read once (the light is the same for the whole wave)
+            const SphereEmitter E = sphere_emitter(L, sph);
+            const float lw = rt_div(1.0f, (float)L.samples);
             V ldir = mk(0, 0, 0), f_d = mk(0, 0, 0), f_s = mk(0, 0, 0);
             float dist = 0.f, d2 = 1.f;
-            if (lit) sphere_light_geometry(sph, p, ldir, dist, d2);
-            const float lw = rt_div(1.0f, (float)L.samples);
-            bool brdf_done = false;
-            for (int ks = kl; ks < kend; ++ks) {
+            if (lit) {
+                sphere_light_geometry(sph, p, ldir, dist, d2);
+                // the BRDF factors do not depend on the sample (a vertex whose samples all face away does not use them)
+                const float4 vm = B.view_mat[v], kds = B.kd_slot[v], ksn = B.ks_n[v];
+                brdf_terms(__float_as_int(vm.w), ksn.w, mk(nk.x, nk.y, nk.z), ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z),
+                           mk(ksn.x, ksn.y, ksn.z), f_d, f_s);
+            }
+            // two samples per round: their arithmetic runs as two-wide packed operations, element for element that of
+            // sphere_light_radiance; the sums are taken in sample order
+            int ks = kl;
+            for (; ks + 1 < kend; ks += 2) {
+                if (!lit) continue;
+                const unsigned k = (unsigned)(k0 + ks);
+                const f2 r1 = f2{rnd(key, DIM_LIGHT + 2 * k), rnd(key, DIM_LIGHT + 2 * k + 2)};
+                const f2 r2 = f2{rnd(key, DIM_LIGHT + 2 * k + 1), rnd(key, DIM_LIGHT + 2 * k + 3)};
+                f2 rx, ry, rz;
+                sphere_light_radiance2(E, ldir, d2, r1, r2, rx, ry, rz);
+                const f2 dx = (f_d.x * rx) * lw, dy = (f_d.y * ry) * lw, dz = (f_d.z * rz) * lw;
+                const f2 sx = (f_s.x * rx) * lw, sy = (f_s.y * ry) * lw, sz = (f_s.z * rz) * lw;
+                if (!(rx.x == 0 && ry.x == 0 && rz.x == 0)) {
+                    ++cnt.shadow;
+                    c = add(c, mk(dx.x, dy.x, dz.x));
+                    c = add(c, mk(sx.x, sy.x, sz.x));
+                }
+                if (!(rx.y == 0 && ry.y == 0 && rz.y == 0)) {
+                    ++cnt.shadow;
+                    c = add(c, mk(dx.y, dy.y, dz.y));
+                    c = add(c, mk(sx.y, sy.y, sz.y));
+                }
+            }
+            for (; ks < kend; ++ks) {   // an odd sample count's last one
                 if (!lit) continue;
                 const unsigned k = (unsigned)(k0 + ks);
                 const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
                 const V rad = sphere_light_radiance(L, sph, ldir, d2, r1, r2);
                 if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
                 ++cnt.shadow;
-                if (!brdf_done) {
-                    brdf_done = true;
-                    const float4 vm = B.view_mat[v], kds = B.kd_slot[v], ksn = B.ks_n[v];
-                    brdf_terms(__float_as_int(vm.w), ksn.w, mk(nk.x, nk.y, nk.z), ldir, mk(vm.x, vm.y, vm.z), mk(kds.x, kds.y, kds.z),
-                               mk(ksn.x, ksn.y, ksn.z), f_d, f_s);
-                }
                 c = add(c, scl(mul(f_d, rad), lw));
                 c = add(c, scl(mul(f_s, rad), lw));
             }

@@ -119,7 +119,6 @@ __device__ __forceinline__ bool slab(float x0, float y0, float z0, float x1, flo
 
 // The same test for the two child boxes of a node at once: every subtraction and multiplication is a two-wide packed
 // operation (L, R).  Element for element the arithmetic is that of slab().
-typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void slab_pair(f2 x0, f2 y0, f2 z0, f2 x1, f2 y1, f2 z1, float ox, float oy, float oz, float ix, float iy,
                                           float iz, bool nx, bool ny, bool nz, float t_hit, float &tl, float &tr, bool &pl, bool &pr) {
     const f2 tx0 = ((nx ? x1 : x0) - ox) * ix, tx1 = ((nx ? x0 : x1) - ox) * ix;
@@ -914,6 +913,57 @@ __device__ __forceinline__ V sphere_light_radiance(const rt_light &L, const rt_s
     const float cos_l = dot(nl, scl(ldir, -1.0f));
     if (cos_l <= 0.0f) return mk(0, 0, 0);
     return scl(mk(L.color), rt_div(L.area * cos_l, d2));
+}
+
+// What a sphere emitter's samples need of the light and its sphere: the same for every lane of a wave, read once per light.
+struct SphereEmitter {
+    float n[9];        // the sphere's normal matrix, rows 0..2, columns 0..2
+    float color[3];
+    float area;
+};
+__device__ __forceinline__ float wave_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ SphereEmitter sphere_emitter(const rt_light &L, const rt_sphere &s) {
+    SphereEmitter e;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) e.n[3 * r + c] = wave_uniform(s.normal[4 * r + c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e.color[c] = wave_uniform(L.color[c]);
+    e.area = wave_uniform(L.area);
+    return e;
+}
+// sphere_light_radiance for two samples at once: element for element the operations of the function above, the
+// multiplications and additions as two-wide packed instructions.  Returns the radiance per colour channel, {sample a,
+// sample b}.
+__device__ __forceinline__ void sphere_light_radiance2(const SphereEmitter &E, V ldir, float d2, f2 ru, f2 rv, f2 &rad_x, f2 &rad_y, f2 &rad_z) {
+    const f2 phi = (2.0f * 3.14159265359f) * ru;
+    const f2 cos_t = 1.0f - 2.0f * rv;
+    const f2 s2 = 1.0f - cos_t * cos_t;
+    const f2 sin_t = f2{rt_sqrt(max_std(0.0f, s2.x)), rt_sqrt(max_std(0.0f, s2.y))};
+    f2 sn, cs;
+    rt_sincos2(phi, sn, cs);
+    const f2 ux = sin_t * cs, uy = sin_t * sn, uz = cos_t;
+    const f2 vx = (E.n[0] * ux + E.n[1] * uy) + E.n[2] * uz;
+    const f2 vy = (E.n[3] * ux + E.n[4] * uy) + E.n[5] * uz;
+    const f2 vz = (E.n[6] * ux + E.n[7] * uy) + E.n[8] * uz;
+    const f2 len2 = (vx * vx + vy * vy) + vz * vz;
+    // normalize(): the zero vector when |v|^2 <= 1e-12, else v * (1 / sqrt(|v|^2))
+    const bool ok0 = len2.x > 1e-12f, ok1 = len2.y > 1e-12f;
+    const f2 inv = f2{ok0 ? rt_div(1.0f, rt_sqrt(len2.x)) : 0.0f, ok1 ? rt_div(1.0f, rt_sqrt(len2.y)) : 0.0f};
+    f2 nx = vx * inv, ny = vy * inv, nz = vz * inv;
+    if (!ok0) nx.x = 0.0f, ny.x = 0.0f, nz.x = 0.0f;
+    if (!ok1) nx.y = 0.0f, ny.y = 0.0f, nz.y = 0.0f;
+    const V toward = scl(ldir, -1.0f);
+    const f2 cos_l = (nx * toward.x + ny * toward.y) + nz * toward.z;
+    const f2 num = E.area * cos_l;
+    const f2 g = f2{cos_l.x <= 0.0f ? 0.0f : rt_div(num.x, d2), cos_l.y <= 0.0f ? 0.0f : rt_div(num.y, d2)};
+    rad_x = E.color[0] * g;
+    rad_y = E.color[1] * g;
+    rad_z = E.color[2] * g;
+    // a sample that faces away returns exactly (0, 0, 0), as the early return of sphere_light_radiance does
+    if (cos_l.x <= 0.0f) rad_x.x = 0.0f, rad_y.x = 0.0f, rad_z.x = 0.0f;
+    if (cos_l.y <= 0.0f) rad_x.y = 0.0f, rad_y.y = 0.0f, rad_z.y = 0.0f;
 }
 
 // `light_sphere`: the sphere of a sphere light (S.spheres[L.sphere] or a staged copy of it); unused otherwise.

@@ -104,6 +104,41 @@ __device__ inline float rt_cos(float x) {
     float y = (j == 1 || j == 2) ? sin_poly(r) : cos_poly(r);
     return neg ? -y : y;
 }
+// Sine and cosine of two angles at once.  Element for element the operations, and so the results, are those of rt_sin
+// and rt_cos: one argument reduction serves both functions (they reduce the same |x|), both polynomials are evaluated
+// for both elements with two-wide packed multiplies and adds, and each result picks its polynomial and sign.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 sin_poly2(f2 x) {
+    const f2 z = x * x;
+    return ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+}
+__device__ __forceinline__ f2 cos_poly2(f2 x) {
+    const f2 z = x * x;
+    return ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+}
+__device__ __forceinline__ void rt_sincos2(f2 x, f2 &sn, f2 &cs) {
+    const f2 ax = f2{absf(x.x), absf(x.y)};
+    const f2 q = ax * 1.27323954473516f;
+    int j0 = (int)q.x, j1 = (int)q.y;
+    j0 += j0 & 1;
+    j1 += j1 & 1;
+    const f2 y = f2{(float)j0, (float)j1};
+    const f2 r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const f2 sp = sin_poly2(r), cp = cos_poly2(r);
+    j0 &= 7;
+    j1 &= 7;
+    // rt_sin: negative argument or octants 4..7 flip the sign; octants 1, 2 (mod 4) take the cosine polynomial
+    // rt_cos: octants 4..7 flip, then octants 2, 3 (mod 4) flip; octants 1, 2 (mod 4) take the sine polynomial
+    const bool hi0 = j0 > 3, hi1 = j1 > 3;
+    const int k0 = hi0 ? j0 - 4 : j0, k1 = hi1 ? j1 - 4 : j1;
+    const bool mid0 = k0 == 1 || k0 == 2, mid1 = k1 == 1 || k1 == 2;
+    const float s0 = mid0 ? cp.x : sp.x, s1 = mid1 ? cp.y : sp.y;
+    const float c0 = mid0 ? sp.x : cp.x, c1 = mid1 ? sp.y : cp.y;
+    const bool sneg0 = (x.x < 0.0f) != hi0, sneg1 = (x.y < 0.0f) != hi1;
+    const bool cneg0 = hi0 != (k0 > 1), cneg1 = hi1 != (k1 > 1);
+    sn = f2{sneg0 ? -s0 : s0, sneg1 ? -s1 : s1};
+    cs = f2{cneg0 ? -c0 : c0, cneg1 ? -c1 : c1};
+}
 __device__ inline float rt_asin(float x) {
     bool neg = x < 0.0f;
     float a = absf(x);
