@@ -7,8 +7,12 @@ torch.distributed / RCCL) the frame is sharded by 32x32 tiles over the ranks and
 inside the timed region (strong scaling: the frame is fixed as N grows).
 
 Prints ONE JSON line on rank 0:
-  value     = rays (primary + shadow + secondary) of all ranks / max-over-ranks wall time, in Mrays/s
-  roofline  = algorithmic traversal+shading bytes of the render kernels / their device time vs HBM peak
+  value     = BVH traversals actually run (camera + bounce paths + shadow rays traced) of all ranks / max-over-ranks
+              wall time, in Mrays/s.  value_reference_equivalent counts the rays the reference's algorithm casts for the
+              same image (every light sample its own shadow ray) over the same time: the unit of cpu_baseline.
+  roofline  = memory-side traffic of the dominant kernel, measured in this run by two rocprofv3 counter passes over one
+              frame (FETCH_SIZE, WRITE_SIZE; child processes, before the timed frames), over its launch time from HIP
+              events in the timed frames, against the HBM peak; next to it the fixed per-ray byte model as a normaliser
   cpu_baseline = the reference renderer (oracle/_ref/raytracer, built from the reference sources)
               or, when absent, the in-repo CPU restatement, timed on this host on a bounded sample
 """
@@ -26,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the eight XCDs
 
 WORKLOADS = {
     # config 4: 1M+ triangle mesh, path traced, 4K, 256 spp
@@ -109,23 +114,87 @@ def kernel_bytes(st, timed):
     }
 
 
-PMC_KERNEL_NAMES = {"generate": "generate_kernel", "trace_closest": "trace_kernel<false, false, true>", "trace_any": "trace_kernel<true, false, true>", "shade": "shade_kernel<true>",
-                    "light_setup": "light_setup_kernel", "light_gather": "light_gather_kernel", "resolve": "resolve_kernel"}
+def pmc_kernel_class(name):
+    """Kernel class (the keys of rt_kernel_times) of a kernel name as rocprofv3 prints it."""
+    if "trace_kernel" in name:
+        return "trace_any" if re.search(r"trace_kernel<\s*true", name) else "trace_closest"
+    for k in ("generate", "shade", "light_setup", "light_gather", "resolve"):
+        if k + "_kernel" in name:
+            return k
+    return None
 
 
-def pmc_traffic(workload, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 counter passes over this benchmark
-    (tools/pmc_traffic_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, reads doubled as gfx950 requires).
-    None when there is no pass for this workload or kernel (a counter pass cannot run inside the timed program)."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_bench.json")
+def pmc_pass(counter, workload, out_dir):
+    """One rocprofv3 counter pass over one frame of `workload` in a child process (this script with
+    --timed-frames-only); returns {kernel class: (sum of the counter over the frame's launches, launches)} or None."""
+    import csv
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    shutil.rmtree(out_dir, ignore_errors=True)
+    cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--timed-frames-only", "--steps", "1", "--warmup", "0", "--workload", workload]
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
-        doc = json.load(open(path))
-    except (OSError, ValueError):
+        child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = child.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, 9)   # the group started above: the profiler and its child
+            child.wait()
+            return None
+        if rc != 0:
+            return None
+        acc, n = {}, {}
+        with open(os.path.join(out_dir, "p_counter_collection.csv")) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = pmc_kernel_class(row["Kernel_Name"])
+                if k:
+                    acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
+                    n[k] = n.get(k, 0) + 1
+        return {k: (acc[k], n[k]) for k in acc}
+    except (OSError, ValueError, KeyError):
         return None
-    if doc.get("workload") != workload or kernel not in PMC_KERNEL_NAMES:
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def measure_traffic(workload):
+    """Memory-side traffic per kernel class and launch, from two counter passes of this run (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass).  FETCH_SIZE tallies 64 bytes per read request of the L2 to the fabric, whatever the request
+    moves; measured on this GPU with known access patterns (tools/calibrate_fetch.sh, profiles/r2_fetch_calibration.json):
+    a gather of 64-byte records, of 16-byte pieces and of whole 128-byte lines all run at the same REQUEST rate (50 G/s
+    from a 2 GiB table, 60 G/s from a 64 MiB one = 8 TB/s of 128-byte lines), so a request occupies the memory side like a
+    128-byte line; a coalesced stream reads 128 bytes per request.  Line-slot bytes = 2 x FETCH_SIZE + WRITE_SIZE;
+    requested bytes count a gathered 64-byte record as 64 (1 x FETCH_SIZE).  Returns None when the profiler is not
+    available or a pass fails."""
+    tmp = os.path.join(tempfile.gettempdir(), f"rt_bench_pmc_{os.getuid()}")
+    fetch = pmc_pass("FETCH_SIZE", workload, tmp + "_f")
+    if fetch is None:
         return None
-    entry = doc.get("kernels", {}).get(PMC_KERNEL_NAMES[kernel])
-    return entry.get("traffic_bytes_per_launch") if entry else None
+    write = pmc_pass("WRITE_SIZE", workload, tmp + "_w")
+    if write is None:
+        return None
+    out = {}
+    for k, (kb, launches) in fetch.items():
+        wkb = write.get(k, (0.0, launches))[0]
+        out[k] = {"launches": launches, "read_requests": kb * 1024.0 / 64.0 / launches, "fetch_size_bytes": kb * 1024.0 / launches,
+                  "write_size_bytes": wkb * 1024.0 / launches}
+    return out
+
+
+def gather_ceiling():
+    """Measured rate of independent 64-byte record gathers from tables of the benchmark tree's size on this GPU model
+    (tools/calibrate_fetch.hip; the committed run): requests per second, or None."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r2_fetch_calibration.json")))
+        rows = [doc[k]["gather64"] for k in ("64", "128")]
+        return min(r["GBps_unprofiled"] for r in rows) * 1e9 / 64.0
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def main():
@@ -135,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "pt1m_4k_256spp"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes (roofline.traffic is then null)")
     ap.add_argument("--timed-frames-only", action="store_true",
                     help="profiling runs: skip the counted frame and the frame without ray sharing (their launches would mix "
                          "into the per-kernel averages); the line then carries the timing only")
@@ -169,6 +239,10 @@ def main():
     w = WORKLOADS[args.workload]
     scene_dir = os.path.join(tempfile.gettempdir(), f"rt_bench_scenes_{os.getuid()}_{rank}")
     path = make_scene(scenegen, scene_dir, w, args.workload)
+    # counter passes first, while this process holds no device memory (the children render the same frame)
+    traffic_by_kernel = None
+    if world == 1 and not args.timed_frames_only and not args.no_pmc:
+        traffic_by_kernel = measure_traffic(args.workload)
     sc = R.Scene(path)
     cam = sc.camera(0)
     ren = R.Renderer(sc)   # scene resident in HBM from here on
@@ -248,41 +322,58 @@ def main():
         # dominant kernel = the kernel class with the largest device time in the timed steps
         name = max(ktimes, key=lambda k: ktimes[k][1])
         launches, total_ms = ktimes[name]
-        per_frame = kernel_bytes(cs, stats)   # algorithmic bytes of each kernel class in one frame
+        per_frame = kernel_bytes(cs, stats)   # fixed per-ray byte model of each kernel class, one frame
         launches_per_frame = launches / args.steps
-        bytes_per_launch = per_frame[name] / launches_per_frame
+        model_bytes_per_launch = per_frame[name] / launches_per_frame
         ms_per_launch = total_ms / launches
-        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
-        traffic = pmc_traffic(args.workload, name) if world == 1 else None
+        model_rate = model_bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+        t = traffic_by_kernel.get(name) if traffic_by_kernel else None
+        roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel_ms_per_launch": ms_per_launch, "launches_per_frame": launches_per_frame,
+                "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()},
+                # the fixed accounting of the reference's two-child walk (32 B per node visit, 36 B per triangle test, ...):
+                # comparable across layouts, but LDS, L1 and L2 serve most of these bytes, so it is no bound of this kernel
+                "byte_model": {"bytes_per_launch": model_bytes_per_launch, "rate_GBps": model_rate,
+                               "ratio_to_hbm_peak": model_rate / HBM_PEAK_GBS, "ratio_to_l2_peak": model_rate / L2_PEAK_GBS,
+                               "note": "normaliser only: bytes of the reference's node-by-node walk, served mostly from LDS/L1/L2"}}
+        if t:
+            sec = ms_per_launch * 1e-3
+            line_slot_bytes = 2.0 * t["fetch_size_bytes"] + t["write_size_bytes"]
+            roof.update({
+                "traffic": line_slot_bytes, "achieved": line_slot_bytes / sec / 1e9, "frac": line_slot_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                "traffic_definition": "memory-side bytes per launch measured in this run: 128 B per L2 read request (2 x FETCH_SIZE; a "
+                                      "request occupies the memory side like a whole line, tools/calibrate_fetch.sh) + WRITE_SIZE",
+                "requested_bytes": t["fetch_size_bytes"] + t["write_size_bytes"],
+                "requested_frac": (t["fetch_size_bytes"] + t["write_size_bytes"]) / sec / 1e9 / HBM_PEAK_GBS,
+                "read_requests_per_launch": t["read_requests"], "read_requests_per_s": t["read_requests"] / sec})
+            ceil = gather_ceiling()
+            if ceil and name.startswith("trace"):
+                roof["gather_ceiling_requests_per_s"] = ceil
+                roof["frac_of_gather_ceiling"] = t["read_requests"] / sec / ceil
+        if traffic_by_kernel:
+            roof["traffic_per_frame_by_kernel"] = {k: (2.0 * v["fetch_size_bytes"] + v["write_size_bytes"]) * v["launches"] for k, v in traffic_by_kernel.items()}
         line = {
-            "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": traced / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "resolution": f"{cam.resx}x{cam.resy}", "spp": cam.num_samples,
                        "triangles": sc.desc.n_triangles, "bvh_nodes": sc.desc.n_bvh_nodes,
                        "renderer": "path tracing" if cam.path_tracing else "whitted", "sharding": f"tiles32/{world}"},
-            # rays as the reference's algorithm casts them (the unit the CPU baseline is counted in) and the
-            # traversals actually run: light samples of a shading point with bit-identical shadow rays share one
-            "ray_accounting": "rays as the reference's algorithm casts them (oracle counters), the unit of cpu_baseline; "
-                              "light samples of a shading point with bit-identical shadow rays share one traversal: "
-                              "traversals_per_frame / value_traversals count traversals run, without_ray_sharing times "
-                              "a frame with sharing off",
-            "rays_per_frame": rays / args.steps, "traversals_per_frame": traced / args.steps,
-            "value_traversals": traced / elapsed / 1e6,
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # the algorithmic bytes are served largely by LDS, L1 and L2, so their rate may pass the HBM peak;
-                         # the HBM-side rate is the measured traffic over the same launch time
-                         "traffic_rate": traffic / (ms_per_launch * 1e-3) / 1e9 if traffic else None,
-                         "traffic_frac": traffic / (ms_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                         "kernel_ms_per_launch": ms_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launches_per_frame": launches_per_frame,
-                         "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()}},
+            "ray_accounting": "value counts the BVH traversals run in the timed frames (camera and bounce paths + shadow rays traced; light "
+                              "samples of a shading point whose shadow rays are identical bit for bit share one).  "
+                              "value_reference_equivalent counts the rays the reference's algorithm casts for the same image (oracle "
+                              "counters: every light sample its own shadow ray) over the same time; it is the unit of cpu_baseline and "
+                              "not a device ray rate.  without_ray_sharing times a frame with sharing off",
+            "traversals_per_frame": traced / args.steps, "reference_rays_per_frame": rays / args.steps,
+            "value_reference_equivalent": rays / elapsed / 1e6,
+            "roofline": roof,
         }
         if unshared_ms:
             line["without_ray_sharing"] = {"ms_per_step": unshared_ms, "value": cs.total_rays / unshared_ms / 1e3}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(R, scenegen, w, scene_dir, None)
+            # same image on both sides: the reference's rays over each side's time
+            line["vs_cpu_baseline"] = line["value_reference_equivalent"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
