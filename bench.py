@@ -209,8 +209,7 @@ def main():
                     help="profiling runs: skip the counted frame and the frame without ray sharing (their launches would mix "
                          "into the per-kernel averages); the line then carries the timing only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --one-device rehearses the multi-rank path on a single GPU")
-    ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
+                    help="torch.distributed backend for the barrier and the timing reductions (the frame's gather is the library's own RCCL)")
     args = ap.parse_args()
 
     import numpy as np
@@ -219,15 +218,13 @@ def main():
 
     import raytracer_amd as R
     from raytracer_amd import scenegen
-    from raytracer_amd.sharding import gather_frame
+    from raytracer_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering core has no CPU fallback")
-    if args.one_device:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -245,15 +242,19 @@ def main():
         traffic_by_kernel = measure_traffic(args.workload)
     sc = R.Scene(path)
     cam = sc.camera(0)
-    ren = R.Renderer(sc)   # scene resident in HBM from here on
+    ren = R.Renderer(sc)   # scene resident in HBM from here on (a full replica on every rank)
 
-    # full-frame device framebuffer (torch is used for device memory and the collective only)
+    # full-frame device framebuffer on rank 0 (torch is used for device memory, the barrier and the timing reductions only)
     fb = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.float32, device="cuda")
-    gathered = None
+    comm = None
+    if world > 1:   # the library's communicator: tiles are rendered per rank and gathered on rank 0 over RCCL
+        comm = R.Comm.init_rank(sharding.exchange_unique_id(rank, world), rank, world)
 
     def step():
-        _, st = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
-        gather_frame(fb, world)   # every rank wrote only its own tiles into a zeroed frame
+        if comm is None:
+            _, st = ren.render(cam, out=fb.data_ptr())
+        else:
+            _, st = ren.render_gather(comm, cam, out=fb.data_ptr())
         return st
 
     def sync():
@@ -263,16 +264,12 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        if world > 1:
-            fb.zero_()
         step()
     sync()
     ren.set_profiling(True)   # HIP events around every kernel launch, on the library's own stream
     traced = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if world > 1:
-            fb.zero_()
         stats = step()
         traced += stats.primary_rays + stats.secondary_rays + stats.shadow_rays_traced
     sync()
@@ -286,6 +283,8 @@ def main():
                               "ms_per_step": elapsed * 1e3 / args.steps, "config": {"workload": args.workload},
                               "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()},
                               "launches_per_frame": {k: v[0] / args.steps for k, v in ktimes.items()}}), flush=True)
+        if comm is not None:
+            comm.close()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -293,7 +292,7 @@ def main():
     # one extra, untimed frame with the work counters on: algorithmic bytes for the roofline.  In this mode every
     # light sample's shadow ray is traversed on its own, which is also the frame time without ray sharing.
     ren.set_counters(True)
-    _, cs = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
+    _, cs = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)   # (rt_render_shard: the rank's tiles at their frame positions)
     ren.set_counters(False)
     # rays of a frame as the reference's algorithm casts them: the counted frame's (same camera, same seed, same tiles);
     # the timed frames do not evaluate the light samples of shading points that a sphere emitter's shadow ray misses
@@ -375,6 +374,8 @@ def main():
             # same image on both sides: the reference's rays over each side's time
             line["vs_cpu_baseline"] = line["value_reference_equivalent"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

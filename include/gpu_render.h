@@ -263,16 +263,42 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 int rt_render(rt_scene *scene, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats);
 
 /* Image-space shard of one frame (32x32 tiles, the reference's square_dynamic tile size,
- * src/main.cpp:441): renders only the tiles owned by `rank` of `world` into hdr_out at their
+ * src/main.cpp:441): renders only the tiles owned by `rank` of `world` (rt_shard_owner_map) into hdr_out at their
  * full-frame positions; other pixels are left untouched. */
 int rt_render_shard(rt_scene *scene, const rt_camera_desc *cam, int32_t rank, int32_t world, float *hdr_out,
                     rt_stats *stats);
 
 /* Host-only helper for the gather step: owner_out[ty*tiles_x + tx] = rank that renders tile (tx, ty) when a
- * resx x resy frame is split over `world` ranks; tiles_x = ceil(resx/32), tiles_y = ceil(resy/32), tile row 0 is
- * the bottom of the image.  Touches no GPU.  (The reference hands tiles to threads dynamically, src/main.cpp:486-
- * 512; a static map is what lets every rank know the layout without communication.) */
+ * resx x resy frame is split over `world` ranks ((tx + skew*ty) mod world with a skew coprime to world, so that the ranks
+ * alternate along rows and columns of tiles and every rank's share is spread over the whole image); tiles_x = ceil(resx/32), tiles_y = ceil(resy/32), tile row 0 is the bottom of the
+ * image.  Touches no GPU.  (The reference hands tiles to threads dynamically, src/main.cpp:486-512; a static map is
+ * what lets every rank know the layout without communication.) */
 int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out);
+
+/* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
+ * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders
+ * the rank's tiles into a packed tile-major buffer, moves the buffers to rank 0 in one grouped RCCL send / receive and,
+ * on rank 0, writes the frame to hdr_out (host or device memory, resx*resy*3 floats; ignored on the other ranks, may be
+ * NULL there).  All ranks of a communicator must make the call for the same camera; it returns when the rank's part is
+ * done.  The frame equals rt_render's (random numbers are keyed by absolute pixel).
+ *   rt_comm_init_all    ranks are threads of this process, rank r on devices[r] (ncclCommInitAll); call
+ *                       rt_render_gather from one thread per rank.  Ranks that share a device (a rehearsal on one GPU)
+ *                       exchange by device-to-device copies instead of RCCL, which allows one rank per device.
+ *   rt_comm_unique_id + rt_comm_init_rank
+ *                       ranks are processes: rank 0 makes the id (RT_COMM_ID_BYTES bytes), the launcher hands it to
+ *                       every rank, each calls rt_comm_init_rank with its device current (ncclCommInitRank). */
+/* Host-only: the layout of the gather.  tiles_of_rank_out[r] = tiles rank r renders; tile_slot_out[ty*tiles_x + tx] = the
+ * tile's slot (units of 32*32*3 floats) in the root's receive buffer, where the tiles of rank r follow those of ranks
+ * 0 .. r-1 and a rank's tiles stand in row-major order, the order in which it packs them.  Touches no GPU. */
+int rt_shard_layout(int32_t resx, int32_t resy, int32_t world, int32_t *tiles_of_rank_out, int32_t *tile_slot_out);
+
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm rt_comm;
+int rt_comm_unique_id(void *id_out, int32_t id_bytes);
+int rt_comm_init_rank(const void *id, int32_t id_bytes, int32_t rank, int32_t world, rt_comm **out);
+int rt_comm_init_all(int32_t n, const int32_t *devices, rt_comm **comms_out);
+int rt_render_gather(rt_scene *scene, rt_comm *comm, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats);
+void rt_comm_destroy(rt_comm *comm);
 
 /* Primary visibility only (bvh::intersect for each pixel's first sample, src/bvh.cpp:383-480):
  * shape index, reference instance id (-1/-1 on a miss) and hit distance (1e30 on a miss); moving objects

@@ -71,6 +71,12 @@ def gpu_lib():
         g.rt_trace_primary.argtypes = [C.c_void_p, C.POINTER(A.CameraDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(A.Stats)]
         g.rt_shard_owner_map.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        g.rt_shard_layout.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        g.rt_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
+        g.rt_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        g.rt_comm_init_all.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        g.rt_render_gather.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(A.CameraDesc), C.c_void_p, C.POINTER(A.Stats)]
+        g.rt_comm_destroy.argtypes = [C.c_void_p]
         g.rt_set_counters.argtypes = [C.c_void_p, C.c_int32]
         g.rt_tonemap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(A.TonemapDesc), C.c_void_p]
         g.rt_tonemap_noalloc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(A.TonemapDesc), C.c_void_p]
@@ -187,6 +193,18 @@ class Renderer:
             self._check(self._g.rt_render_shard(self._ptr, C.byref(cam), rank, world, ptr, C.byref(stats)), "rt_render_shard")
         return out, stats
 
+    def render_gather(self, comm, cam, out=None):
+        """This rank's part of a frame that is split over the ranks of `comm` (rt_render_gather).  On rank 0 returns
+        (frame, Stats) like render(); on the other ranks (None, Stats).  Every rank of the communicator must call it."""
+        stats = A.Stats()
+        ptr = None
+        if comm.rank == 0:
+            if out is None:
+                out = np.zeros((cam.resy, cam.resx, 3), dtype=np.float32)
+            ptr = out if isinstance(out, int) else out.ctypes.data
+        self._check(self._g.rt_render_gather(self._ptr, comm._ptr, C.byref(cam), ptr, C.byref(stats)), "rt_render_gather")
+        return (out if comm.rank == 0 else None), stats
+
     def trace_primary(self, cam):
         n = cam.resx * cam.resy
         shape = np.empty(n, dtype=np.int32)
@@ -207,6 +225,43 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """One rank's end of a communicator for tile-sharded frames (rt_comm_*)."""
+
+    def __init__(self, ptr, rank, world):
+        self._g = gpu_lib()
+        self._ptr = C.c_void_p(ptr)
+        self.rank, self.world = rank, world
+
+    @classmethod
+    def init_all(cls, devices):
+        """Ranks as threads of this process, rank r on devices[r]; ranks that share a device (a rehearsal on one GPU)
+        exchange by device-to-device copies.  Returns one Comm per rank."""
+        g = gpu_lib()
+        n = len(devices)
+        devs = (C.c_int32 * n)(*devices)
+        ptrs = (C.c_void_p * n)()
+        if g.rt_comm_init_all(n, devs, ptrs) != 0:
+            raise RaytracerError("rt_comm_init_all: " + g.rt_last_error().decode())
+        return [cls(ptrs[r], r, n) for r in range(n)]
+
+    @classmethod
+    def init_rank(cls, unique_id, rank, world):
+        """This process as rank `rank` of `world` (one process per GPU, the current device); `unique_id` from
+        sharding.exchange_unique_id."""
+        g = gpu_lib()
+        ptr = C.c_void_p()
+        buf = (C.c_ubyte * len(unique_id)).from_buffer_copy(unique_id) if unique_id else None
+        if g.rt_comm_init_rank(buf, len(unique_id) if unique_id else 0, rank, world, C.byref(ptr)) != 0:
+            raise RaytracerError("rt_comm_init_rank: " + g.rt_last_error().decode())
+        return cls(ptr.value, rank, world)
+
+    def close(self):
+        if self._ptr:
+            self._g.rt_comm_destroy(self._ptr)
+            self._ptr = C.c_void_p()
 
 
 def gpu_tonemap(hdr, tmo, opt1, opt2, saturation, gamma):

@@ -129,12 +129,13 @@ struct Batch {
     int n_pixels;                 // tile_count * 1024 (pixel-local indices, including out-of-image ones)
     int n_samples, grid_n;
     int tiles_x;
-    int rank, world;
+    const int *owned;             // this rank's tiles (row-major tile numbers, ascending); null: every tile, in order
     int still;                    // 1: rays carry time 0 whatever the camera sampled (primary-visibility queries)
 };
 
 __device__ __forceinline__ void batch_pixel(const Batch &b, int pl, int &i, int &j) {
-    const int tile = (b.tile_first + (pl >> 10)) * b.world + b.rank;
+    const int at = b.tile_first + (pl >> 10);
+    const int tile = b.owned ? b.owned[at] : at;
     const int tx = tile % b.tiles_x, ty = tile / b.tiles_x;
     const int in = pl & 1023, quad = in >> 8, wave = (in >> 6) & 3, lane = in & 63;
     i = tx * TILE + (quad & 1) * 16 + (wave & 1) * 8 + (lane & 7);
@@ -1117,7 +1118,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
 }
 
 // ---- resolve: per-sample clamp (src/ray_trace.cpp:1158-1167) and the pixel mean (src/main.cpp:464-483) --------------
-__global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch b, Wavefront W, float *__restrict__ out) {
+// `packed`: the frame goes out tile by tile, tile t of the rank's list at floats [t * 3072, (t + 1) * 3072), pixels row-major
+// inside the tile (what the ranks of a multi-GPU frame send to the root); otherwise at its place in the full frame.
+__global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch b, Wavefront W, float *__restrict__ out, int packed) {
     const int pl = blockIdx.x * 256 + threadIdx.x;
     if (pl >= b.n_pixels) return;
     int i, j;
@@ -1137,7 +1140,8 @@ __global__ void __launch_bounds__(256) resolve_kernel(rt_camera_desc cam, Batch 
         a2 += bl;
     }
     const float ns = (float)b.n_samples;
-    float *dst = out + ((size_t)j * cam.resx + i) * 3;
+    float *dst = packed ? out + ((size_t)(b.tile_first + (pl >> 10)) * (TILE * TILE) + (size_t)((j % TILE) * TILE + (i % TILE))) * 3
+                        : out + ((size_t)j * cam.resx + i) * 3;
     dst[0] = rt_div(a0, ns);
     dst[1] = rt_div(a1, ns);
     dst[2] = rt_div(a2, ns);
@@ -1231,6 +1235,11 @@ struct rt_scene {
     int slot_table = -1;              // offset of the deferred-mode slot table in light_of
     std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
+    // this rank's tiles of a frame that is split over several ranks (see shard_owner)
+    int *owned_tiles = nullptr;       // device copy of the list
+    size_t owned_room = 0;
+    int owned_key[4] = {0, 0, 0, 0};  // resx, resy, rank, world the list was built for
+    int n_owned = 0;
     unsigned trace_blocks[2][3] = {{0, 0, 0}, {0, 0, 0}};   // resident workgroups of trace_kernel<ANY, ...> (plain, counting, wide), a multiple of N_SHARDS
     // per-kernel timing (rt_set_profiling): every launch bracketed by two events on `stream`
     bool profiling = false;
@@ -1822,6 +1831,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (s->host_flags) (void)hipHostFree(s->host_flags);
     if (s->stats) (void)hipFree(s->stats);
     if (s->framebuffer) (void)hipFree(s->framebuffer);
+    if (s->owned_tiles) (void)hipFree(s->owned_tiles);
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->shaded) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->lit) (void)hipEventDestroy(e);
@@ -1854,6 +1864,55 @@ int rt_kernel_times(const rt_scene *s, rt_kernel_time *out) {
 int rt_set_counters(rt_scene *s, int32_t enabled) {
     if (!s) return 1;
     s->counters = enabled != 0;
+    return 0;
+}
+
+// Which rank renders tile (tx, ty) of a frame split over `world` ranks: (tx + skew * ty) mod world, with a skew that is
+// coprime to world (the one nearest to 0.38 * world).  Along a row of tiles, and along a column, the ranks follow each
+// other cyclically, so every rank's share is spread over the whole image and the shares are even whatever the frame's
+// width in tiles; numbering the tiles row by row instead would hand a rank whole columns of tiles whenever the number of
+// ranks divides the width.  (The reference hands tiles to its threads dynamically, src/main.cpp:486-512; a static rule
+// lets every rank know the layout without a message.)
+static inline int shard_skew(int world) {
+    auto gcd = [](int a, int b) {
+        while (b) {
+            const int t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    int s = std::max(1, (int)(0.381966f * (float)world + 0.5f));
+    while (gcd(s, world) != 1) ++s;
+    return s;
+}
+static inline int shard_owner(int tx, int ty, int world) { return (int)(((long long)tx + (long long)shard_skew(world) * ty) % world); }
+
+// Builds (and keeps on the device) the list of tiles `rank` of `world` renders, in row-major order.  With one rank the
+// list is implicit.
+static int ensure_owned_tiles(rt_scene *s, int resx, int resy, int rank, int world) {
+    const int tiles_x = (resx + TILE - 1) / TILE, tiles_y = (resy + TILE - 1) / TILE;
+    if (world == 1) {
+        s->n_owned = tiles_x * tiles_y;
+        return 0;
+    }
+    const int key[4] = {resx, resy, rank, world};
+    if (s->owned_tiles && memcmp(key, s->owned_key, sizeof key) == 0) return 0;
+    std::vector<int> list;
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx)
+            if (shard_owner(tx, ty, world) == rank) list.push_back(ty * tiles_x + tx);
+    if (list.size() + 1 > s->owned_room) {
+        HIP_OK(hipStreamSynchronize(s->stream));
+        if (s->owned_tiles) (void)hipFree(s->owned_tiles);
+        s->owned_tiles = nullptr;
+        s->owned_room = 0;
+        HIP_OK(hipMalloc((void **)&s->owned_tiles, (list.size() + 1) * sizeof(int)));
+        s->owned_room = list.size() + 1;
+    }
+    if (!list.empty()) HIP_OK(hipMemcpy(s->owned_tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
+    memcpy(s->owned_key, key, sizeof key);
+    s->n_owned = (int)list.size();
     return 0;
 }
 
@@ -1904,23 +1963,20 @@ static void read_stats(rt_scene *s, rt_stats *st, float kernel_ms, float total_m
     st->total_ms = total_ms;
 }
 
-int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_t world, float *hdr_out, rt_stats *stats) {
-    if (!s || !cam || !hdr_out) {
-        g_error = "rt_render: null argument";
-        return 1;
-    }
-    if (world < 1 || rank < 0 || rank >= world) {
-        g_error = "rt_render_shard: rank/world out of range";
-        return 1;
-    }
+}  // extern "C"
+
+// Renders the tiles of `rank` of `world` into device memory: at their places in the full frame `dev_out` (resx * resy * 3
+// floats; other pixels untouched), or with `packed` tile after tile in the order of the rank's list (3072 floats per tile).
+// Returns with the stream drained; kernel_ms = device time between the first and the last kernel.
+static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int world, float *dev_out, bool packed, float &kernel_ms) {
     int grid_n, n_samples;
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
-    auto t0 = std::chrono::high_resolution_clock::now();
     HIP_OK(hipSetDevice(s->device));
     if (int rc = account_paths(s, (unsigned long long)cam->resx * cam->resy * n_samples / world)) return rc;
-    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
-    const int total_tiles = tiles_x * tiles_y;
-    const int n_owned = total_tiles > rank ? (total_tiles - rank + world - 1) / world : 0;
+    const int tiles_x = (cam->resx + TILE - 1) / TILE;
+    if (int rc = ensure_owned_tiles(s, cam->resx, cam->resy, rank, world)) return rc;
+    const int n_owned = s->n_owned;
+    const int *owned = world == 1 ? nullptr : s->owned_tiles;
     const bool pt = cam->path_tracing != 0;
     // queue growth bound per camera sample: splitting fans out at depth 0, dielectrics may double per bounce
     unsigned growth = (unsigned)(pt && cam->splitting_factor > 1 ? cam->splitting_factor : 1) * (s->has_dielectric ? 2u : 1u);
@@ -1941,24 +1997,6 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         return 5;
     }
 
-    // output: device pointer -> write in place; host pointer -> internal framebuffer + copy back
-    hipPointerAttribute_t attr;
-    bool out_on_device = false;
-    if (hipPointerGetAttributes(&attr, hdr_out) == hipSuccess) out_on_device = attr.type == hipMemoryTypeDevice;
-    (void)hipGetLastError();
-    const size_t n_floats = (size_t)cam->resx * cam->resy * 3;
-    float *dev_out = hdr_out;
-    if (!out_on_device) {
-        if (s->framebuffer_floats < n_floats) {
-            if (s->framebuffer) (void)hipFree(s->framebuffer);
-            s->framebuffer = nullptr;
-            s->framebuffer_floats = 0;
-            HIP_OK(hipMalloc((void **)&s->framebuffer, n_floats * sizeof(float)));
-            s->framebuffer_floats = n_floats;
-        }
-        dev_out = s->framebuffer;
-        if (world > 1) HIP_OK(hipMemcpyAsync(dev_out, hdr_out, n_floats * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    }
     HIP_OK(hipMemsetAsync(s->stats, 0, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
 
@@ -1991,8 +2029,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         b.n_samples = n_samples;
         b.grid_n = grid_n;
         b.tiles_x = tiles_x;
-        b.rank = rank;
-        b.world = world;
+        b.owned = owned;
         b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
         HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
@@ -2040,7 +2077,7 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
         {
             LaunchTimer timer(s, RT_KERNEL_RESOLVE, s->stream);
-            hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out);
+            hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out, packed ? 1 : 0);
         }
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
@@ -2060,10 +2097,57 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
         tile += tiles_now;
     }
     HIP_OK(hipEventRecord(s->ev1, s->stream));
-    if (!out_on_device) HIP_OK(hipMemcpyAsync(hdr_out, dev_out, n_floats * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
-    float kernel_ms = 0.f;
+    kernel_ms = 0.f;
     HIP_OK(hipEventElapsedTime(&kernel_ms, s->ev0, s->ev1));
+    return 0;
+}
+
+// A device buffer of the scene that holds at least `n_floats` floats (grown when needed, kept).
+static int scene_buffer(rt_scene *s, float *&buf, size_t &room, size_t n_floats) {
+    if (room >= n_floats && buf) return 0;
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    room = 0;
+    HIP_OK(hipMalloc((void **)&buf, std::max<size_t>(n_floats, 1) * sizeof(float)));
+    room = n_floats;
+    return 0;
+}
+
+static bool on_device(const void *p) {
+    hipPointerAttribute_t attr;
+    const bool dev = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    return dev;
+}
+
+extern "C" {
+
+int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_t world, float *hdr_out, rt_stats *stats) {
+    if (!s || !cam || !hdr_out) {
+        g_error = "rt_render: null argument";
+        return 1;
+    }
+    if (world < 1 || rank < 0 || rank >= world) {
+        g_error = "rt_render_shard: rank/world out of range";
+        return 1;
+    }
+    auto t0 = std::chrono::high_resolution_clock::now();
+    HIP_OK(hipSetDevice(s->device));
+    // output: device pointer -> write in place; host pointer -> internal framebuffer + copy back
+    const bool out_on_device = on_device(hdr_out);
+    const size_t n_floats = (size_t)std::max(cam->resx, 0) * (size_t)std::max(cam->resy, 0) * 3;
+    float *dev_out = hdr_out;
+    if (!out_on_device && n_floats) {
+        if (int rc = scene_buffer(s, s->framebuffer, s->framebuffer_floats, n_floats)) return rc;
+        dev_out = s->framebuffer;
+        if (world > 1) HIP_OK(hipMemcpyAsync(dev_out, hdr_out, n_floats * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    }
+    float kernel_ms = 0.f;
+    if (int rc = render_tiles(s, cam, rank, world, dev_out, false, kernel_ms)) return rc;
+    if (!out_on_device) HIP_OK(hipMemcpy(hdr_out, dev_out, n_floats * sizeof(float), hipMemcpyDeviceToHost));
     auto t1 = std::chrono::high_resolution_clock::now();
     read_stats(s, stats, kernel_ms, (float)std::chrono::duration<double, std::milli>(t1 - t0).count());
     return 0;
@@ -2071,15 +2155,16 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
 
 int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats) { return rt_render_shard(s, cam, 0, 1, hdr_out, stats); }
 
-// Host-only: which rank renders which 32x32 tile.  Must stay the inverse of batch_pixel()'s
-// `tile = owned_index * world + rank`.
+// Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major
+// order, which is the order of its packed buffer.
 int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out) {
     if (resx < 1 || resy < 1 || world < 1 || !owner_out) {
         g_error = "rt_shard_owner_map: bad argument";
         return 1;
     }
     const int tiles_x = (resx + TILE - 1) / TILE, tiles_y = (resy + TILE - 1) / TILE;
-    for (int k = 0; k < tiles_x * tiles_y; ++k) owner_out[k] = k % world;
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx) owner_out[ty * tiles_x + tx] = shard_owner(tx, ty, world);
     return 0;
 }
 
@@ -2122,8 +2207,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
         b.n_samples = 1;
         b.grid_n = grid_n;
         b.tiles_x = tiles_x;
-        b.rank = 0;
-        b.world = 1;
+        b.owned = nullptr;
         b.still = 1;
         const unsigned slots = (unsigned)b.n_pixels;
         HIP_OK(hipMemsetAsync(W.counters, 0, (COUNTER_WORDS - 1) * sizeof(unsigned), s->stream));   // all but the overflow flag
@@ -2174,3 +2258,4 @@ int rt_selftest_math(int32_t fn, int32_t n, const float *a, const float *b, floa
 }  // extern "C"
 
 #include "rt_tonemap.h"
+#include "rt_gather.h"

@@ -5,7 +5,8 @@
 // the reference (src/main.cpp:437-555) is replaced by one rt_render() call per camera; the threading
 // arguments are still parsed and validated so existing invocations keep working, but they no longer
 // select anything — the GPU schedules the pixels.  RT_GPU=<index> picks the device; without it the files of a
-// directory are spread over all visible GPUs.
+// directory are spread over all visible GPUs (frame -> GPU).  RT_GPUS=<n> makes the first n GPUs a team that renders
+// every frame together: each GPU its share of the 32x32 tiles, gathered on the first over RCCL (rt_render_gather).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -121,10 +122,28 @@ static void job_printf(FileJob &job, const char *fmt, ...) {
 
 class Pipeline {
 public:
-    Pipeline(std::vector<std::string> files, int thread_count, int threading_type, std::vector<int> gpus)
-        : thread_count_(thread_count), threading_type_(threading_type), gpus_(std::move(gpus)) {
+    // `team`: with more than one device, every frame is split by tiles over these devices (and `gpus` is the team's
+    // first device alone); empty: every render thread renders whole frames on its own device
+    Pipeline(std::vector<std::string> files, int thread_count, int threading_type, std::vector<int> gpus, std::vector<int> team = {})
+        : thread_count_(thread_count), threading_type_(threading_type), gpus_(std::move(gpus)), team_(std::move(team)) {
         jobs_.resize(files.size());
         for (size_t i = 0; i < files.size(); ++i) jobs_[i].path = files[i];
+    }
+    ~Pipeline() {
+        for (rt_comm *c : comms_) rt_comm_destroy(c);
+    }
+
+    // false (with a message) when the team's communicators cannot be made
+    bool prepare() {
+        if (team_.size() < 2) return true;
+        comms_.assign(team_.size(), nullptr);
+        std::vector<int32_t> devices(team_.begin(), team_.end());
+        if (rt_comm_init_all((int32_t)devices.size(), devices.data(), comms_.data()) != 0) {
+            log_printf("Error: cannot set up %zu GPUs for tile-sharded frames: %s\n", team_.size(), rt_last_error());
+            comms_.clear();
+            return false;
+        }
+        return true;
     }
 
     void run() {
@@ -238,10 +257,65 @@ private:
         }
         rt_scene_desc desc = job.scene.desc();
         rt_scene *gpu = nullptr;
-        if (rt_scene_create(&desc, &gpu) != 0) {
-            job_printf(job, "rt_scene_create failed: %s\n", rt_last_error());
+        // A team of GPUs: the other ranks run beside this thread, each with its own replica of the scene, and meet it in
+        // rt_render_gather camera by camera.  They start rendering only when every replica exists.
+        const size_t n_ranks = comms_.empty() ? 1 : comms_.size();
+        struct Team {
+            std::mutex m;
+            std::condition_variable cv;
+            size_t created = 0, failed = 0;
+            std::vector<std::vector<rt_stats>> stats;   // [camera][rank], filled as the ranks finish a camera
+            std::vector<size_t> reported;               // [camera]: ranks that have
+            std::string error;
+        } team;
+        team.stats.assign(job.scene.cameras.size(), std::vector<rt_stats>(n_ranks));
+        team.reported.assign(job.scene.cameras.size(), 0);
+        std::vector<std::thread> helpers;
+        for (size_t r = 1; r < n_ranks; ++r)
+            helpers.emplace_back([&, r] {
+                rt_scene *mine = nullptr;
+                bool ok = hipSetDevice(team_[r]) == hipSuccess && rt_scene_create(&desc, &mine) == 0;
+                {
+                    std::unique_lock<std::mutex> lk(team.m);
+                    if (!ok) {
+                        ++team.failed;
+                        team.error = rt_last_error();
+                    }
+                    ++team.created;
+                    team.cv.notify_all();
+                    team.cv.wait(lk, [&] { return team.created == n_ranks; });
+                    ok = team.failed == 0;
+                }
+                for (size_t k = 0; ok && k < job.scene.cameras.size(); ++k) {
+                    rt_stats st{};
+                    if (rt_render_gather(mine, comms_[r], &job.scene.cameras[k].desc, nullptr, &st) != 0) {
+                        fprintf(stderr, "rt_render_gather failed on GPU %d: %s\n", team_[r], rt_last_error());
+                        _exit(255);   // the other ranks wait for this one's tiles: the reference's way out of a failed render
+                    }
+                    std::lock_guard<std::mutex> lk(team.m);
+                    team.stats[k][r] = st;
+                    ++team.reported[k];
+                    team.cv.notify_all();
+                }
+                if (mine) rt_scene_destroy(mine);
+            });
+        const bool created = rt_scene_create(&desc, &gpu) == 0;
+        {
+            std::unique_lock<std::mutex> lk(team.m);
+            if (!created) {
+                ++team.failed;
+                team.error = rt_last_error();
+            }
+            ++team.created;
+            team.cv.notify_all();
+            team.cv.wait(lk, [&] { return team.created == n_ranks; });
+        }
+        if (team.failed) {
+            for (auto &t : helpers) t.join();
+            job_printf(job, "rt_scene_create failed: %s\n", team.error.c_str());
             fail(index, -1);
         }
+        size_t camera_index = 0;
         auto end = std::chrono::high_resolution_clock::now();
         job_printf(job, "JSON parsing and grid preparation is done: %d ms\n",
                    (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - job.start).count());
@@ -268,10 +342,26 @@ private:
                 frame = device_frame;
             }
             rt_stats stats;
-            if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
-                job_printf(job, "rt_render failed: %s\n", rt_last_error());
-                fail(index, -1);
+            if (n_ranks == 1) {
+                if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
+                    job_printf(job, "rt_render failed: %s\n", rt_last_error());
+                    fail(index, -1);
+                }
+            } else {
+                if (rt_render_gather(gpu, comms_[0], &cam.desc, frame, &stats) != 0) {
+                    fprintf(stderr, "rt_render_gather failed: %s\n", rt_last_error());
+                    _exit(255);
+                }
+                std::unique_lock<std::mutex> lk(team.m);   // the frame is complete; the other ranks' ray counts follow
+                team.cv.wait(lk, [&] { return team.reported[camera_index] == n_ranks - 1; });
+                for (size_t r = 1; r < n_ranks; ++r) {
+                    stats.primary_rays += team.stats[camera_index][r].primary_rays;
+                    stats.shadow_rays += team.stats[camera_index][r].shadow_rays;
+                    stats.secondary_rays += team.stats[camera_index][r].secondary_rays;
+                    stats.kernel_ms = std::max(stats.kernel_ms, team.stats[camera_index][r].kernel_ms);
+                }
             }
+            ++camera_index;
             end = std::chrono::high_resolution_clock::now();
             job_printf(job, "%s rendering done: %d ms\n", name.c_str(), (int)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count());
             const unsigned long long rays = stats.primary_rays + stats.shadow_rays + stats.secondary_rays;
@@ -312,6 +402,7 @@ private:
             if (timing) job_printf(job, "[timing] camera total %.1f ms (render + tone map + hand-off)\n", since(start));
         }
         auto t_destroy = std::chrono::high_resolution_clock::now();
+        for (auto &t : helpers) t.join();
         rt_scene_destroy(gpu);
         if (timing) job_printf(job, "[timing] destroy %.1f ms, scene total on the render thread %.1f ms\n", since(t_destroy), since(t_begin));
     }
@@ -356,7 +447,8 @@ private:
     }
 
     int thread_count_, threading_type_;
-    std::vector<int> gpus_;
+    std::vector<int> gpus_, team_;
+    std::vector<rt_comm *> comms_;   // one per rank of the team
     std::vector<FileJob> jobs_;
     std::vector<WriteTask> write_queue_;
     std::mutex m_;
@@ -409,8 +501,34 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (gpus.size() > files.size()) gpus.resize(std::max<size_t>(1, files.size()));
+    // RT_GPUS=<n>: GPUs 0 .. n-1 render every frame together, split by 32x32 tiles (a single heavy frame is the case for
+    // it; a directory of light frames is served better by the default, one frame per GPU).  RT_GPUS_DEVICES="0,0,0" names
+    // the team's devices instead (a repeated device rehearses the path on one GPU).
+    std::vector<int> team;
+    if (const char *names = getenv("RT_GPUS_DEVICES")) {
+        for (const char *p = names; *p;) {
+            team.push_back(atoi(p));
+            const char *comma = strchr(p, ',');
+            if (!comma) break;
+            p = comma + 1;
+        }
+    } else if (const char *n = getenv("RT_GPUS")) {
+        int visible = 0;
+        if (hipGetDeviceCount(&visible) != hipSuccess) visible = 0;
+        const int want = atoi(n);
+        if (want < 1 || want > visible) {
+            log_printf("Error: RT_GPUS=%s but %d GPU(s) are visible\n", n, visible);
+            return 1;
+        }
+        for (int g = 0; g < want; ++g) team.push_back(g);
+    }
+    if (team.size() > 1) gpus.assign(1, team[0]);
     const auto t_run = std::chrono::high_resolution_clock::now();
-    Pipeline(files, thread_count, tt, gpus).run();
+    {
+        Pipeline pipeline(files, thread_count, tt, gpus, team);
+        if (!pipeline.prepare()) return 1;
+        pipeline.run();
+    }
     if (getenv("RT_CLI_TIMING"))
         log_printf("[timing] %zu file(s) in %.1f ms\n", files.size(),
                    std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_run).count());

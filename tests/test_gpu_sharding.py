@@ -48,6 +48,100 @@ def test_exact_scene_shards_are_bitwise(scene_dir):
     assert again.tobytes() == full.tobytes()
 
 
+def gathered_frame(sc, cam, world, frames=1):
+    """`frames` frames of `cam` through rt_render_gather with `world` ranks that are threads of this process, all on
+    device 0 (each with its own replica of the scene): what the command line does with one GPU per rank."""
+    import threading
+    comms = R.Comm.init_all([0] * world)
+    rens = [R.Renderer(sc) for _ in range(world)]
+    out, stats, errors = [None] * frames, [[None] * world for _ in range(frames)], []
+
+    def work(rank):
+        try:
+            for f in range(frames):
+                img, st = rens[rank].render_gather(comms[rank], cam)
+                stats[f][rank] = st
+                if rank == 0:
+                    out[f] = img
+        except Exception as e:   # a failed rank must not leave the others waiting unnoticed
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads), "a rank is stuck in the gather"
+    for c in comms:
+        c.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_gathered_frame_equals_single_render_bitwise(world, scene_dir):
+    """The tile-sharded, gathered frame against rt_render, byte for byte: 1 spp with point lights gives every pixel one
+    add per light in a fixed order, so nothing depends on who renders a tile.  Ragged frame (15 x 9 tiles, the last
+    column and row cut), two frames in a row through the same communicator."""
+    sc = R.Scene(scenegen.write_mesh_scene(scene_dir, n=188, width=470, height=265))
+    cam = sc.camera(0)
+    full, st = R.Renderer(sc).render(cam)
+    frames, stats = gathered_frame(sc, cam, world, frames=2)
+    for img, per_rank in zip(frames, stats):
+        assert img.tobytes() == full.tobytes()
+        assert sum(s.total_rays for s in per_rank) == st.total_rays
+        counts, _ = sharding.layout(cam.resx, cam.resy, world)
+        assert [s.primary_rays > 0 for s in per_rank] == [c > 0 for c in counts]
+
+
+@pytest.mark.parametrize("name,world", [("pathtrace", 2), ("textured", 3), ("materials", 8)])
+def test_gathered_frame_equals_single_render(name, world, scene_dir):
+    """Branching and stochastic scenes: the same paths whoever renders them; sums inside a sample may re-associate
+    between runs (float atomics), which bounds the difference at 1e-5."""
+    sc = R.Scene(GS.SCENES[name][0](scene_dir))
+    cam = sc.camera(0)
+    full, st = R.Renderer(sc).render(cam)
+    (img,), (per_rank,) = gathered_frame(sc, cam, world)
+    err = np.abs(img - full) / np.maximum(np.abs(full), 1 / 255)
+    assert err.max() <= 1e-5
+    assert sum(s.total_rays for s in per_rank) == st.total_rays
+
+
+def test_single_rank_communicator_over_rccl(scene_dir):
+    """One process per GPU, as under torchrun: the id comes from RCCL (ncclGetUniqueId), the communicator from
+    ncclCommInitRank -- here with a single rank, which is all one GPU allows -- and the frame through rt_render_gather."""
+    sc = R.Scene(scenegen.write_mesh_scene(scene_dir, n=188, width=470, height=265))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    full, st = ren.render(cam)
+    comm = R.Comm.init_rank(sharding.exchange_unique_id(0, 1), 0, 1)
+    img, sg = ren.render_gather(comm, cam)
+    assert img.tobytes() == full.tobytes() and sg.total_rays == st.total_rays
+    comm.close()
+    plain = R.Comm.init_rank(None, 0, 1)               # and without an id: no RCCL at all
+    img2, _ = ren.render_gather(plain, cam)
+    assert img2.tobytes() == full.tobytes()
+    plain.close()
+
+
+def test_command_line_team_of_ranks(tmp_path, scene_dir, repo_root):
+    """./raytracer with a team of three ranks (all on GPU 0: RT_GPUS_DEVICES) splits each camera's frame by tiles and
+    gathers it; the PNG equals the one a single GPU writes."""
+    import os
+    import subprocess
+    from test_host import png_pixels
+    exe = os.path.join(repo_root, "raytracer")
+    path = scenegen.write_mesh_scene(scene_dir, name="team", n=188, width=470, height=265)
+    for sub, env in (("one", {}), ("team", {"RT_GPUS_DEVICES": "0,0,0"})):
+        cwd = tmp_path / sub
+        cwd.mkdir()
+        r = subprocess.run([exe, path], cwd=cwd, capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "team.png rendering done:" in r.stdout
+    assert np.array_equal(png_pixels(str(tmp_path / "one" / "outputs" / "team.png")), png_pixels(str(tmp_path / "team" / "outputs" / "team.png")))
+    assert png_pixels(str(tmp_path / "one" / "outputs" / "team.png")).std() > 5
+
+
 def test_full_size_path_traced_frame_properties(scene_dir):
     """1M-triangle scene at 3840x2160 (4 spp to keep the test short; per-sample work is what 256 spp repeats)."""
     path = scenegen.write_path_traced_scene(scene_dir, name="pt1m_props", n=710, width=3840, height=2160, spp=4, max_depth=4)

@@ -1,8 +1,10 @@
-"""Tile sharding and the framebuffer gather with two processes over gloo (no GPU).
+"""Tile sharding and the framebuffer gather without a GPU: the layout the library computes (who owns which tile, where
+a tile lands in the root's receive buffer) and, with two processes over gloo, the exchange itself.
 
-Each rank takes the same full CPU image (rendered by the test oracle, standing in for the device), keeps only the
-pixels of the tiles it owns according to rt_shard_owner_map -- what rt_render_shard writes -- and the ranks run
-the product's gather.  Rank 0 must end up with the single-rank image byte for byte."""
+In the two-process test each rank takes the same full CPU image (rendered by the test oracle, standing in for the
+device), packs the tiles it owns the way the device's resolve kernel does, rank 1 sends its buffer to rank 0 (what the
+library does with one grouped ncclSend / ncclRecv) and rank 0 unpacks by the library's slot table.  Rank 0 must end up
+with the single-rank image byte for byte."""
 import os
 import socket
 import sys
@@ -20,17 +22,53 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from raytracer_amd import sharding  # noqa: E402
 
 
-@pytest.mark.parametrize("res,world", [((64, 64), 1), ((1920, 1080), 2), ((3840, 2160), 8), ((97, 33), 3), ((5, 7), 4)])
+def skew(world):
+    import math
+    s = max(1, int(0.381966 * world + 0.5))
+    while math.gcd(s, world) != 1:
+        s += 1
+    return s
+
+
+@pytest.mark.parametrize("res,world", [((64, 64), 1), ((1920, 1080), 2), ((3840, 2160), 8), ((97, 33), 3), ((5, 7), 4), ((3840, 2160), 3)])
 def test_owner_map_partitions_the_frame(res, world):
     own = sharding.owner_map(res[0], res[1], world)
     assert own.shape == ((res[1] + 31) // 32, (res[0] + 31) // 32)
     assert own.min() >= 0 and own.max() < world
     masks = np.stack([sharding.pixel_mask(res[0], res[1], r, world) for r in range(world)])
     assert (masks.sum(axis=0) == 1).all()                       # every pixel has exactly one owner
-    counts = np.bincount(own.ravel(), minlength=world)
-    assert counts.max() - counts.min() <= 1                     # tiles are dealt round-robin
-    # round-robin in row-major tile order (what the device kernel inverts: tile = owned_index * world + rank)
-    assert np.array_equal(own.ravel(), np.arange(own.size) % world)
+    # the rule: ranks follow each other along a row of tiles, shifted by a skew coprime to their number from row to row
+    want = np.array([[(tx + skew(world) * ty) % world for tx in range(own.shape[1])] for ty in range(own.shape[0])])
+    assert np.array_equal(own, want)
+    if world > 1 and min(own.shape) >= world:                   # shares are even to within one row of tiles, and no rank owns a
+        counts = np.bincount(own.ravel(), minlength=world)      # whole column or row of tiles
+        assert counts.max() - counts.min() <= max(own.shape) // world + 1
+        for r in range(world):
+            assert not (own == r).all(axis=0).any() and not (own == r).all(axis=1).any()
+
+
+@pytest.mark.parametrize("res", [(64, 64), (1920, 1080), (97, 33), (5, 7)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_gather_layout_is_a_bijection(res, world):
+    """Every tile has exactly one slot in the root's buffer; rank r's slots follow those of ranks below it and keep the
+    row-major order of the rank's own list."""
+    counts, slot = sharding.layout(res[0], res[1], world)
+    own = sharding.owner_map(res[0], res[1], world)
+    assert counts.sum() == own.size and np.array_equal(counts, np.bincount(own.ravel(), minlength=world))
+    assert np.array_equal(np.sort(slot.ravel()), np.arange(own.size))
+    first = np.concatenate([[0], np.cumsum(counts)])
+    for r in range(world):
+        mine = slot.ravel()[own.ravel() == r]                   # row-major walk over the rank's tiles
+        assert np.array_equal(mine, first[r] + np.arange(counts[r]))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_pack_then_unpack_is_the_frame(world):
+    rng = np.random.default_rng(world)
+    frame = rng.random((70, 100, 3), dtype=np.float32)          # 4 x 3 tiles, ragged on both axes
+    gathered = np.concatenate([sharding.pack_tiles(frame, r, world) for r in range(world)])
+    assert gathered.shape[0] == 12
+    assert sharding.unpack_tiles(gathered, 100, 70, world).tobytes() == frame.tobytes()
 
 
 def _worker(rank, world, port, full_path, out_path):
@@ -39,11 +77,18 @@ def _worker(rank, world, port, full_path, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full = np.load(full_path)
     h, w = full.shape[:2]
-    mine = np.where(sharding.pixel_mask(w, h, rank, world)[:, :, None], full, np.float32(0))
-    fb = torch.from_numpy(np.ascontiguousarray(mine))
-    sharding.gather_frame(fb, world)
+    counts, _ = sharding.layout(w, h, world)
+    mine = torch.from_numpy(sharding.pack_tiles(full, rank, world))
+    assert mine.shape[0] == counts[rank]
     if rank == 0:
-        np.save(out_path, fb.numpy())
+        parts = [mine]
+        for r in range(1, world):
+            buf = torch.empty((int(counts[r]), 32, 32, 3), dtype=torch.float32)
+            dist.recv(buf, src=r)
+            parts.append(buf)
+        np.save(out_path, sharding.unpack_tiles(torch.cat(parts).numpy(), w, h, world))
+    else:
+        dist.send(mine, dst=0)
     dist.barrier()
     dist.destroy_process_group()
 
