@@ -40,7 +40,7 @@ RcclApi *rccl_api() {
         // process may hold a second ROCm installation, e.g. the one a Python package ships), then the loader's choice
         std::vector<std::string> names;
         Dl_info info;
-        if (dladdr((void *)&hipMalloc, &info) && info.dli_fname) {
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
             std::string dir(info.dli_fname);
             const size_t slash = dir.rfind('/');
             if (slash != std::string::npos) {
