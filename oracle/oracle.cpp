@@ -389,8 +389,8 @@ struct Tracer {
                 }
                 if (!got) return h;
             }
-            if (cur < 0) {   // leaf reference: 1 << 31 | (n - 1) << 24 | first entry
-                const int n = (((unsigned)cur >> 24) & 0x7f) + 1, first = cur & 0xffffff;
+            if (cur < 0) {   // leaf reference: 1 << 31 | first entry (on the device the last entry carries an end mark)
+                const int first = cur & 0x7fffffff, n = S.nodes[(size_t)S.leaf_node_at[(size_t)first]].n_prims;
                 // the leaf's own (exact) box decides whether its entries are tested, as in the two-child walk: the
                 // quantised boxes only decide what is looked at
                 ++cnt.nodes;
@@ -1637,7 +1637,7 @@ long orc_wide_check(orc_scene *s, long *n_records) {
                 if (ref != rt::WIDE_REF_NONE) ++bad;
             } else if (N[slot[k]].n_prims > 0) {
                 ++leaves_seen;
-                if ((unsigned)ref != (0x80000000u | ((unsigned)(N[slot[k]].n_prims - 1) << 24) | (unsigned)N[slot[k]].offset)) ++bad;
+                if ((unsigned)ref != (0x80000000u | (unsigned)N[slot[k]].offset)) ++bad;
             } else {
                 todo.push_back({ref, slot[k]});
             }

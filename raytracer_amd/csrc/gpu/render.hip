@@ -68,7 +68,9 @@ thread_local std::string g_error;
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 6
 #endif
-constexpr int MAX_GENERATIONS = 66;   // queue generations per batch (depth limit + 2)
+// Queue generations a batch can have: path depths 0 .. ceil(MaxRecursionDepth), plus the children the last one appends.
+// The depth travels in 16 bits of a path record; the append counters are allocated for what the scene asks for.
+constexpr int MAX_DEPTH = 65000;
 
 struct PathQueue {
     float4 *o_time;     // origin.xyz, ray time
@@ -107,7 +109,8 @@ struct Wavefront {
     ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
     unsigned shadow_shard_entries;   // shadow rays, and light-sample records, per shard
     float *accum;             // radiance sums per slot: three planes (r, g, b) of `capacity` floats
-    unsigned *counters;       // [3 kinds][MAX_GENERATIONS + 1][N_SHARDS] entry counts, one 128-byte line each
+    unsigned *counters;       // [3 kinds][generations][N_SHARDS] entry counts, one 128-byte line each, then the overflow flag
+    int generations;          // generations the counters have room for
     unsigned *overflow;       // set when a queue ran out of room
     unsigned shard_entries;   // path / vertex entries per shard
     unsigned capacity;        // N_SHARDS * shard_entries = slots of the accumulator
@@ -121,7 +124,7 @@ constexpr int N_SHARDS = 64;
 constexpr int COUNTER_STRIDE = 32;   // in 4-byte words
 enum { Q_PATH = 0, Q_VERTEX = 1, Q_SHADOW = 2 };
 __device__ __forceinline__ unsigned *counter_of(const Wavefront &W, int kind, int gen, int shard) {
-    return W.counters + ((size_t)(kind * (MAX_GENERATIONS + 1) + gen) * N_SHARDS + shard) * COUNTER_STRIDE;
+    return W.counters + ((size_t)(kind * W.generations + gen) * N_SHARDS + shard) * COUNTER_STRIDE;
 }
 
 struct Batch {
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
 #endif
         if (run_leaf) {
             if (r.cur < 0) {
-                const int k = r.cur & 0xffffff;
+                const int k = r.cur & LEAF_ENTRY_MASK;
                 const float4 *entry = S.prims + PRIM_STRIDE * (size_t)k;   // one 64-byte block, read at once
                 const float4 p0 = entry[0], p1 = entry[1], p2 = entry[2];
                 bool inside = true;
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                         ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                         r.cur = REF_IDLE;
                     } else {
-                        r.cur = ((r.cur >> 24) & 0x7f) ? r.cur - (1 << 24) + 1 : REF_POP;
+                        r.cur = (__float_as_int(p2.y) & PRIM_LAST_BIT) ? REF_POP : r.cur + 1;
                     }
                 }
 #ifndef RT_NO_INLINE_POP
@@ -1211,7 +1214,7 @@ template <class T> int upload(const T *src, size_t n, T **dst) {
 struct rt_scene {
     DevScene dev{};
     std::vector<void *> allocations;
-    unsigned long long *stats = nullptr;   // STAT_ROWS x STAT_WORDS device counters
+    unsigned long long *stats = nullptr;   // STAT_ROWS x STAT_WORDS device counters, followed by a copy taken before the current batch
     float *framebuffer = nullptr;
     size_t framebuffer_floats = 0;
     bool counters = false;
@@ -1291,7 +1294,7 @@ static void harvest_timers(rt_scene *s) {
     s->events_used = 0;
 }
 
-constexpr int COUNTER_WORDS = 3 * (MAX_GENERATIONS + 1) * N_SHARDS * COUNTER_STRIDE + 1;   // append counters + overflow flag
+static size_t counter_words(int generations) { return (size_t)3 * generations * N_SHARDS * COUNTER_STRIDE + 1; }   // append counters + overflow flag
 
 // Upper bound of entries per path queue / vertex buffer / accumulator.  An entry costs 348 bytes plus 136 bytes per
 // shadow slot (`shadow_mult` slots per entry: rays and light-sample records of one vertex in one lighting pass, both
@@ -1314,7 +1317,7 @@ static unsigned wavefront_capacity(unsigned shadow_mult) {
 }
 
 // Allocates the wavefront state for `cap` entries; on failure everything allocated so far is released.
-static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, Wavefront &W) {
+static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, int generations, Wavefront &W) {
     auto alloc = [&](void **p, size_t bytes) -> bool {
         if (hipMalloc(p, bytes) != hipSuccess) return false;
         s->wf_allocations.push_back(*p);
@@ -1333,7 +1336,7 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, W
              alloc((void **)&W.shadow[k].fs_, scap * 16) && alloc((void **)&W.shadow[k].vis, scap * 4);
     }
     ok = ok && alloc((void **)&W.hit_t, (size_t)cap * 4) && alloc((void **)&W.hit_prim, (size_t)cap * 4) &&
-         alloc((void **)&W.accum, (size_t)cap * 12) && alloc((void **)&W.counters, COUNTER_WORDS * sizeof(unsigned));
+         alloc((void **)&W.accum, (size_t)cap * 12) && alloc((void **)&W.counters, counter_words(generations) * sizeof(unsigned));
     if (!ok) {
         for (void *p : s->wf_allocations) (void)hipFree(p);
         s->wf_allocations.clear();
@@ -1341,7 +1344,8 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, W
         return 10;
     }
     W.shadow_shard_entries = (unsigned)(scap / N_SHARDS);
-    W.overflow = W.counters + COUNTER_WORDS - 1;
+    W.generations = generations;
+    W.overflow = W.counters + counter_words(generations) - 1;
     W.shard_entries = cap / N_SHARDS;
     W.capacity = cap;
     return 0;
@@ -1388,13 +1392,14 @@ static bool park_wavefront(rt_scene *s) {
 // Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries and `shadow_floor` shadow slots
 // (what one batch of the smallest size needs); grows, never shrinks.  A new state gets `shadow_mult` shadow slots per
 // entry.  When the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
-static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned shadow_mult, unsigned long long shadow_floor) {
+static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned shadow_mult, unsigned long long shadow_floor, int generations) {
     // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
     const unsigned long long unit = N_SHARDS * 256;
     wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
     unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity(shadow_mult));
     auto enough = [&](const Wavefront &W) {
-        return W.capacity >= cap && (unsigned long long)W.shadow_shard_entries * N_SHARDS >= std::min<unsigned long long>(shadow_floor, (unsigned long long)cap * shadow_mult);
+        return W.capacity >= cap && W.generations >= generations &&
+               (unsigned long long)W.shadow_shard_entries * N_SHARDS >= std::min<unsigned long long>(shadow_floor, (unsigned long long)cap * shadow_mult);
     };
     if (enough(s->wf)) return 0;
     if (!s->host_flags) HIP_OK(hipHostMalloc((void **)&s->host_flags, sizeof(unsigned)));
@@ -1409,7 +1414,7 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned sha
     s->wf = Wavefront{};
     for (;;) {
         Wavefront W{};
-        if (allocate_wavefront(s, cap, shadow_mult, W) == 0) {
+        if (allocate_wavefront(s, cap, shadow_mult, std::max(generations, 8), W) == 0) {
             s->wf = W;
             return 0;
         }
@@ -1498,7 +1503,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     for (int i = 0; i < d->n_bvh_prims; ++i) {
         const rt_bvh_prim &p = d->bvh_prims[i];
         bool ok = p.shape >= 0 && p.shape < d->n_triangles + d->n_spheres &&
-                  (p.shape >= d->n_triangles || (p.instance >= 0 && p.instance < d->n_instances && p.instance < PRIM_XFORM_BIT));
+                  (p.shape >= d->n_triangles ? p.shape - d->n_triangles <= PRIM_INDEX_MASK
+                                             : (p.instance >= 0 && p.instance < d->n_instances && p.instance <= PRIM_INDEX_MASK));
         if (!ok) {
             g_error = "rt_scene_create: BVH primitive out of range";
             return 3;
@@ -1506,8 +1512,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
     for (int i = 0; i < d->n_bvh_nodes; ++i) {
         const rt_bvh_node &n = d->bvh_nodes[i];
-        bool ok = n.n_prims > 0 ? (n.offset >= 0 && n.offset + n.n_prims <= d->n_bvh_prims && n.n_prims <= 0xffff)
-                                : (n.offset > i && n.offset < d->n_bvh_nodes && i + 1 < d->n_bvh_nodes && n.axis >= 0 && n.axis < 3);
+        // (a leaf may hold any number of entries; the reference's own count is 16 bits wide, src/bvh.h:20)
+        bool ok = n.n_prims > 0    ? (n.offset >= 0 && (long long)n.offset + n.n_prims <= d->n_bvh_prims)
+                  : n.n_prims == 0 ? (n.offset > i && n.offset < d->n_bvh_nodes && i + 1 < d->n_bvh_nodes && n.axis >= 0 && n.axis < 3)
+                                   : false;
         if (!ok) {
             g_error = "rt_scene_create: malformed BVH node";
             return 3;
@@ -1603,15 +1611,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
                 }
             }
         }
-        bool ok = true;
         auto ref_of = [&](int i) -> int {
             const rt_bvh_node &n = d->bvh_nodes[i];
             if (n.n_prims == 0) return interior_index[i];
-            if (n.n_prims > 128 || n.offset >= (1 << 24)) {
-                ok = false;
-                return 0;
-            }
-            return (int)(0x80000000u | ((unsigned)(n.n_prims - 1) << 24) | (unsigned)n.offset);
+            return (int)(0x80000000u | (unsigned)n.offset);
         };
         nodes.resize((size_t)n_interior * 4);
         for (int i = 0; i < d->n_bvh_nodes; ++i) {
@@ -1631,11 +1634,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             o[3] = make_float4(fl, fr, fa, 0.f);
         }
         if (d->n_bvh_nodes > 0) root_ref = ref_of(0);
-        if (!ok) {
-            g_error = "rt_scene_create: a BVH leaf holds more than 128 primitives or the scene has more than 16M leaf entries";
-            delete s;
-            return 3;
-        }
     }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
@@ -1660,21 +1658,27 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             const rt_instance &in = d->instances[p.instance];
             const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
             prim_meta[2 * (size_t)i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, t.smooth ? 1 : 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(prim_meta[2 * (size_t)i].x), 0.f, 0.f);
+            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), 0.f, 0.f);
         } else {
             prims[PRIM_STRIDE * i] = make_float4(0, 0, 0, 0);
             prims[PRIM_STRIDE * i + 1] = make_float4(0, 0, 0, 0);
             prim_meta[2 * (size_t)i] = make_int4(-1 - (p.shape - d->n_triangles), p.shape, 123456, 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float(prim_meta[2 * (size_t)i].x), 0.f, 0.f);
+            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float((int)(0x80000000u | (unsigned)(p.shape - d->n_triangles))), 0.f, 0.f);
         }
         prims[PRIM_STRIDE * i + 3] = make_float4(0, 0, 0, 0);
     }
-    for (int i = 0; i < d->n_bvh_nodes; ++i) {   // every entry carries the box of its leaf
+    for (int i = 0; i < d->n_bvh_nodes; ++i) {   // every entry carries the box of its leaf, the last one says that it is
         const rt_bvh_node &n = d->bvh_nodes[i];
         for (int k = 0; k < n.n_prims; ++k) {
             float4 *e = &prims[PRIM_STRIDE * (size_t)(n.offset + k)];
             e[2].z = n.bmin[0], e[2].w = n.bmin[1];
             e[3] = make_float4(n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]);
+            if (k == n.n_prims - 1) {
+                int word;
+                memcpy(&word, &e[2].y, 4);
+                word |= PRIM_LAST_BIT;
+                memcpy(&e[2].y, &word, 4);
+            }
         }
     }
     std::vector<float4> inst((size_t)d->n_instances * 4);
@@ -1763,7 +1767,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.bg, d->background_color, sizeof D.bg);
     D.bg_tex = d->background_texture;
     D.is_probe = d->is_probe;
-    if (hipMalloc((void **)&s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+    if (hipMalloc((void **)&s->stats, 2 * STAT_ROWS * STAT_WORDS * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
         hipStreamCreate(&s->stream2) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         g_error = "rt_scene_create: cannot allocate stream/events";
@@ -1927,8 +1931,8 @@ static int check_camera(const rt_scene *s, const rt_camera_desc *cam, int &grid_
         grid_n = (int)sqrt((double)cam->num_samples);   // src/camera.cpp:149
         n_samples = grid_n * grid_n;
     }
-    if (!(s->dev.max_depth <= (float)(MAX_GENERATIONS - 2))) {
-        g_error = "MaxRecursionDepth exceeds the supported " + std::to_string(MAX_GENERATIONS - 2) + " queue generations";
+    if (!(s->dev.max_depth <= (float)MAX_DEPTH)) {   // (the reference takes any value, src/parser.cpp:1253-1258; its recursion would not)
+        g_error = "MaxRecursionDepth exceeds the supported " + std::to_string(MAX_DEPTH) + " path generations";
         return 5;
     }
     if (cam->splitting_factor > 4096) {
@@ -1989,7 +1993,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     const unsigned slots_per_vertex = (unsigned)(share_rays ? s->k_pad_deferred : s->k_pad);   // shadow slots of a vertex in one pass
     const int slot_table = share_rays ? s->slot_table : -1;
     if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex,
-                                  1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024))
+                                  1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024, std::max(1, (int)ceilf(s->dev.max_depth) + 2)))
         return rc;
     const Wavefront &W = s->wf;
     if ((unsigned long long)n_samples * 1024ull > W.capacity) {
@@ -2032,7 +2036,9 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         b.owned = owned;
         b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
-        HIP_OK(hipMemsetAsync(W.counters, 0, COUNTER_WORDS * sizeof(unsigned), s->stream));
+        HIP_OK(hipMemsetAsync(W.counters, 0, counter_words(W.generations) * sizeof(unsigned), s->stream));
+        // the frame's counters as they stand before this batch, should the batch have to be done again
+        HIP_OK(hipMemcpyAsync(s->stats + STAT_ROWS * STAT_WORDS, s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
         {
             LaunchTimer timer(s, RT_KERNEL_GENERATE, s->stream);
             hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
@@ -2058,7 +2064,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             const int n_pass = (s->k_total + 63) / 64;
             for (int pass = 0; pass < n_pass; ++pass) {
                 if (pass > 0)
-                    HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * (MAX_GENERATIONS + 1) + gen) * N_SHARDS * COUNTER_STRIDE, 0,
+                    HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                 {
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
@@ -2083,15 +2089,18 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
         harvest_timers(s);
-        if (*s->host_flags) {   // a queue ran out of room: redo this batch with fewer camera samples in flight
+        if (*s->host_flags) {   // a queue ran out of room: this batch again, with fewer camera samples in flight
             if (tiles_now == 1 && growth > 4096) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
                 return 6;
             }
             growth *= 2;
-            // ray counters of the abandoned attempt are not separable; the frame's counters restart
-            HIP_OK(hipMemsetAsync(s->stats, 0, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), s->stream));
-            tile = 0;
+            // a small frame got a small wavefront state: let it hold at least one tile at the new bound
+            if (int rc = ensure_wavefront(s, 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex, 1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024,
+                                          std::max(1, (int)ceilf(s->dev.max_depth) + 2)))
+                return rc;
+            // only this batch is done again (its tiles are simply resolved a second time); the abandoned attempt's counts go
+            HIP_OK(hipMemcpyAsync(s->stats, s->stats + STAT_ROWS * STAT_WORDS, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
             continue;
         }
         tile += tiles_now;
@@ -2179,7 +2188,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
     if (int rc = account_paths(s, (unsigned long long)cam->resx * cam->resy)) return rc;
     const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
     const int total_tiles = tiles_x * tiles_y;
-    if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull, 1, 0)) return rc;
+    if (int rc = ensure_wavefront(s, (unsigned long long)total_tiles * 1024ull, 1, 0, 2)) return rc;
     const Wavefront &W = s->wf;
     const size_t n = (size_t)cam->resx * cam->resy;
     int32_t *d_shape = nullptr, *d_id = nullptr;
@@ -2210,7 +2219,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera_desc *cam, int32_t *shape_out,
         b.owned = nullptr;
         b.still = 1;
         const unsigned slots = (unsigned)b.n_pixels;
-        HIP_OK(hipMemsetAsync(W.counters, 0, (COUNTER_WORDS - 1) * sizeof(unsigned), s->stream));   // all but the overflow flag
+        HIP_OK(hipMemsetAsync(W.counters, 0, (counter_words(W.generations) - 1) * sizeof(unsigned), s->stream));   // all but the overflow flag
         hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
         const unsigned grid = std::min(4096u / N_SHARDS, std::max(1u, (slots / N_SHARDS + 255) / 256)) * N_SHARDS;
         launch_trace(s, s->stream, false, grid, 0, 0);

@@ -21,11 +21,14 @@ enum {
 // ---- device-resident scene -------------------------------------------------------------------
 // nodes:  4 x float4 per INTERIOR BVH node, holding the boxes of both children:
 //         {Lmin.xyz, Lmax.x} {Lmax.yz, Rmin.xy} {Rmin.z, Rmax.xyz} {bits(Lref), bits(Rref), bits(1 << split axis), 0}
-//         child ref >= 0: interior node index; < 0: leaf = 1<<31 | (n_prims - 1) << 24 | first leaf entry
+//         child ref >= 0: interior node index; < 0: leaf = 1<<31 | first leaf entry (the leaf's last entry says so itself)
 // prims:  4 x float4 (one 64-byte block) per leaf entry, in leaf order; the last 24 bytes hold the box of the leaf the
 //         entry belongs to, so that the wide walk's exact leaf test and the first entry's test read the same block:
-//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(instance), leaf min.xy} {leaf min.z, leaf max.xyz}
-//         sphere   {...unused...}                 {0, bits(-1 - sphere), leaf min.xy} {leaf min.z, leaf max.xyz}
+//         triangle {c1s.xyz, e1.x} {e1.yz, e2.xy} {e2.z, bits(entry word), leaf min.xy} {leaf min.z, leaf max.xyz}
+//         sphere   {...unused...}                 {0, bits(entry word), leaf min.xy}    {leaf min.z, leaf max.xyz}
+//         entry word: bit 31 sphere, bit 30 the placement moves or transforms the ray, bit 29 last entry of its leaf, bits 0..28
+//         placement (triangles) or sphere index.  A leaf holds as many entries as the tree gives it (the reference's count is
+//         16 bits wide, src/bvh.h:20)
 // prim_meta: 2 x int4 per leaf entry: what shading needs of a hit entry, in one 32-byte block:
 //         {bits(instance) as above, shape, reference id, smooth shading?} {flat normal.xyz, 0}
 // inst:   4 x float4 per placement {inv row0} {inv row1} {inv row2} {motionblur.xyz, bits(flags)}
@@ -89,7 +92,7 @@ struct Hit {
 // The traversal is cut into steps (ray set-up, pop, interior-node step, one primitive test) that the trace
 // kernel schedules per wave; a lane's position is its `cur` reference:
 //   0 <= cur < REF_POP   interior node to visit
-//   cur < 0              leaf: 1<<31 | (entries left - 1) << 24 | next leaf entry
+//   cur < 0              leaf: 1<<31 | next leaf entry
 //   REF_POP              take the next node from the stack
 //   REF_IDLE             no ray
 #ifndef RT_LDS_STACK
@@ -100,7 +103,10 @@ constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = 
 constexpr int REF_POP = 0x40000000;
 constexpr int REF_IDLE = 0x40000001;
 constexpr int PRIM_STRIDE = 4;   // float4 per leaf entry: one 64-byte block
-constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's placement index: the placement moves or transforms the ray
+constexpr int PRIM_XFORM_BIT = 0x40000000;   // in a leaf entry's word (and the shading record's placement): the placement moves or transforms the ray
+constexpr int PRIM_LAST_BIT = 0x20000000;    // in a leaf entry's word: the last entry of its leaf
+constexpr int PRIM_INDEX_MASK = 0x1fffffff;  // placement or sphere index
+constexpr int LEAF_ENTRY_MASK = 0x7fffffff;  // in a leaf reference: the entry
 
 // Box test of intersect_aabb_fast without its final (t_min < t_hit) term; returns the entry distance.  The
 // reference narrows [t_min, t_max] axis by axis and leaves as soon as the interval is empty; for ordered operands
@@ -365,7 +371,7 @@ __device__ __forceinline__ bool prim_test(const DevScene &S, float4 p0, float4 p
         const V ro = mk(r.ox, r.oy, r.oz), rd = mk(r.dx, r.dy, r.dz);
         V oo = ro, dd = rd;
         if (inst & PRIM_XFORM_BIT) {
-            const float4 *ip = S.inst + 4 * (size_t)(inst & ~PRIM_XFORM_BIT);
+            const float4 *ip = S.inst + 4 * (size_t)(inst & PRIM_INDEX_MASK);
             const float4 r3 = ip[3];
             const int flags = __float_as_int(r3.w);
             V moved = ro;
@@ -405,7 +411,7 @@ __device__ __forceinline__ bool prim_test(const DevScene &S, float4 p0, float4 p
     }
     // sphere::intersect, src/shapes.cpp:407-447
     if (COUNT) ++c.sph;
-    const rt_sphere &sp_ = S.spheres[-1 - inst];
+    const rt_sphere &sp_ = S.spheres[inst & PRIM_INDEX_MASK];
     const V so = xpoint(sp_.inv_model, mk(r.ox, r.oy, r.oz));
     const V sd = xdir(sp_.inv_model, mk(r.dx, r.dy, r.dz));
     const V oc = sub(so, mk(sp_.center));

@@ -25,8 +25,8 @@ inline void wide_slots(const rt_bvh_node *N, int i, int slot[4], int axis_of[3])
     if (N[R].n_prims == 0) slot[2] = R + 1, slot[3] = N[R].offset, axis_of[2] = N[R].axis; else slot[2] = R, slot[3] = -1;
 }
 
-// Fills the record headed by node i (`index`: node -> record); false when a box is not finite, a leaf too large or the
-// grid cannot hold the boxes.
+// Fills the record headed by node i (`index`: node -> record); false when a box is not finite or the grid cannot hold
+// the boxes.
 inline bool fill_wide_record(const rt_bvh_node *N, int i, const std::vector<int> &index, WideRecord &rec_out) {
     auto as_float = [](unsigned v) {
         float f;
@@ -46,8 +46,7 @@ inline bool fill_wide_record(const rt_bvh_node *N, int i, const std::vector<int>
         if (c.n_prims == 0) {
             ref[k] = (unsigned)index[slot[k]];
         } else {
-            if (c.n_prims > 128 || c.offset >= (1 << 24)) return false;
-            ref[k] = 0x80000000u | ((unsigned)(c.n_prims - 1) << 24) | (unsigned)c.offset;
+            ref[k] = 0x80000000u | (unsigned)c.offset;   // the leaf's first entry; its last entry carries the end mark
         }
     }
     for (int a = 0; a < 3; ++a) {

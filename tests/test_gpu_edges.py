@@ -86,6 +86,38 @@ def test_small_queues_force_batches_and_retries(name, scene_dir, monkeypatch):
     assert err.max() <= 1e-5
 
 
+def test_leaf_with_two_hundred_entries(tmp_path):
+    """200 coincident triangles have one centroid, so the builder cannot split them (src/bvh.cpp:150-300) and they share
+    one leaf; the reference's leaf count is 16 bits wide (src/bvh.h:20).  Both walks against the oracle."""
+    def edit(s):
+        s["Objects"]["Mesh"]["Faces"]["_data"] = "3 1 2  1 3 4 " + " 5 6 7" * 200
+        del s["Objects"]["Triangle"]
+    path = patched(os.path.join(ROOT, "scenes", "simple.json"), str(tmp_path / "pile.json"), edit)
+    sc = R.Scene(path)
+    _, meta, prims = sc.bvh_arrays()
+    assert meta[:, 1].max() >= 200                                  # (offset, n_prims, axis): one leaf holds the pile
+    first_of_pile = prims[meta[np.argmax(meta[:, 1]), 0], 0]
+    img, st = same_as_oracle(path)                                  # the counted walk, visit for visit
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    fast, sf = ren.render(cam)                                      # the timed path
+    assert sf.nodes_visited == 0 and np.abs(fast - img).max() <= 1e-5 * max(1.0, float(img.max()))
+    shape, ids, t, _ = ren.trace_primary(cam)
+    s0, i0, t0, _ = Oracle(sc).trace_primary(cam)
+    assert np.array_equal(shape, s0) and np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+    pile = (shape >= 2) & (shape < 202)                              # (shapes 0, 1: the quad; 202: the sphere)
+    assert pile.sum() >= 4 and set(shape[pile]) == {first_of_pile}   # of equal hits the leaf's first entry is kept
+
+
+def test_recursion_depth_beyond_sixty_four(scene_dir, tmp_path):
+    """MaxRecursionDepth 100 (the reference takes any value, src/parser.cpp:1253-1258): mirrors and glass against the oracle."""
+    def edit(s):
+        s["MaxRecursionDepth"] = "100"
+    path = patched(GS.SCENES["materials"][0](scene_dir), str(tmp_path / "deep.json"), edit)
+    _, st = same_as_oracle(path)
+    assert st.secondary_rays > 0
+
+
 def test_rejected_descriptions():
     g = R.gpu_lib()
     sc = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
