@@ -23,6 +23,8 @@ int32_t rth_scene_camera_count(const rth_scene *s);
 const rt_camera_desc *rth_scene_camera(const rth_scene *s, int32_t index);
 const char *rth_scene_image_name(const rth_scene *s, int32_t index);
 int32_t rth_scene_tonemap_count(const rth_scene *s, int32_t camera);
+/* The file-name extension of tone map `index` of `camera` (the scene file's Tonemap.Extension, e.g. "_phot.png"). */
+const char *rth_scene_tonemap_extension(const rth_scene *s, int32_t camera, int32_t index);
 /* ingest and BVH-build wall time in milliseconds */
 void rth_scene_timings(const rth_scene *s, double *ingest_ms, double *bvh_ms);
 void rth_scene_free(rth_scene *s);

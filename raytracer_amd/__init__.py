@@ -40,6 +40,8 @@ def host_lib():
         h.rth_scene_image_name.restype = C.c_char_p
         h.rth_scene_image_name.argtypes = [C.c_void_p, C.c_int32]
         h.rth_scene_tonemap_count.argtypes = [C.c_void_p, C.c_int32]
+        h.rth_scene_tonemap_extension.restype = C.c_char_p
+        h.rth_scene_tonemap_extension.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         h.rth_scene_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         h.rth_scene_free.argtypes = [C.c_void_p]
         h.rth_tonemap.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p,
@@ -121,6 +123,9 @@ class Scene:
 
     def tonemap_count(self, camera=0):
         return self._h.rth_scene_tonemap_count(self._ptr, camera)
+
+    def tonemap_extension(self, camera, index):
+        return self._h.rth_scene_tonemap_extension(self._ptr, camera, index).decode()
 
     def tonemap(self, camera, index, hdr):
         hdr = np.ascontiguousarray(hdr, dtype=np.float32)
@@ -285,8 +290,9 @@ def gpu_quantize_ldr(hdr):
 
 
 def write_outputs(scene, camera_index, hdr, out_dir="outputs"):
-    """Writes the images the reference writes for one camera (src/main.cpp:561-607): EXR when the
-    image name ends in .exr, else a plain PNG when there are no tone maps; one PNG per tone map."""
+    """Writes the images the reference writes for one camera (src/main.cpp:561-607): an EXR when the camera is HDR or the
+    image name ends in .exr, else a plain PNG when the camera has no tone maps; and one PNG per tone map
+    (`<base><Extension>`).  Returns the paths written."""
     h = host_lib()
     os.makedirs(out_dir, exist_ok=True)
     name = scene.image_name(camera_index)
@@ -294,7 +300,7 @@ def write_outputs(scene, camera_index, hdr, out_dir="outputs"):
     H, W = hdr.shape[:2]
     written = []
     ntm = scene.tonemap_count(camera_index)
-    if name.endswith(".exr"):
+    if name.endswith(".exr") or scene.camera(camera_index).is_hdr:
         path = os.path.join(out_dir, name)
         h.rth_write_exr(os.fsencode(path), W, H, hdr.ctypes.data)
         written.append(path)
@@ -302,6 +308,12 @@ def write_outputs(scene, camera_index, hdr, out_dir="outputs"):
         ldr = np.empty(hdr.shape, dtype=np.uint8)
         h.rth_quantize_ldr(hdr.size, hdr.ctypes.data, ldr.ctypes.data)
         path = os.path.join(out_dir, name)
+        h.rth_write_png(os.fsencode(path), W, H, ldr.ctypes.data, 1)
+        written.append(path)
+    base = name[:name.rfind(".")] if "." in name else name
+    for k in range(ntm):
+        ldr = scene.tonemap(camera_index, k, hdr)
+        path = os.path.join(out_dir, base + scene.tonemap_extension(camera_index, k))
         h.rth_write_png(os.fsencode(path), W, H, ldr.ctypes.data, 1)
         written.append(path)
     return written

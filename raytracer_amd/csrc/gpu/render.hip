@@ -1570,7 +1570,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
 
     rt_scene *s = new rt_scene();
-    HIP_OK(hipGetDevice(&s->device));
+    if (hipError_t e = hipGetDevice(&s->device); e != hipSuccess) {
+        g_error = std::string("hipGetDevice: ") + hipGetErrorString(e);
+        delete s;
+        return 10;
+    }
     DevScene &D = s->dev;
     auto keep = [&](void *p) { s->allocations.push_back(p); };
 

@@ -49,6 +49,12 @@ int32_t rth_scene_tonemap_count(const rth_scene *s, int32_t camera) {
     if (camera < 0 || camera >= (int32_t)s->scene.cameras.size()) return 0;
     return (int32_t)s->scene.cameras[camera].tonemaps.size();
 }
+const char *rth_scene_tonemap_extension(const rth_scene *s, int32_t camera, int32_t index) {
+    if (camera < 0 || camera >= (int32_t)s->scene.cameras.size()) return "";
+    const auto &tms = s->scene.cameras[camera].tonemaps;
+    if (index < 0 || index >= (int32_t)tms.size()) return "";
+    return tms[index].extension.c_str();
+}
 void rth_scene_timings(const rth_scene *s, double *ingest_ms, double *bvh_ms) {
     if (ingest_ms) *ingest_ms = s->scene.ingest_ms;
     if (bvh_ms) *bvh_ms = s->scene.bvh_ms;

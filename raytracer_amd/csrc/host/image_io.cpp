@@ -216,42 +216,60 @@ bool decode_exr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         err = "tiled EXR not supported";
         return false;
     }
+    // Every size and offset below comes from the file: each is checked against what the file holds before it is used.
     size_t p = 8;
     struct Chan {
         std::string name;
         int type;
     };
     std::vector<Chan> chans;
-    int compression = 0, xmin = 0, ymin = 0, xmax = -1, ymax = -1;
-    auto cstr = [&](std::string &s) {
+    int compression = 0;
+    int64_t xmin = 0, ymin = 0, xmax = -1, ymax = -1;
+    auto cstr = [&](std::string &s) {   // false when the string runs off the end of the file
         s.clear();
         while (p < file.size() && file[p]) s += (char)file[p++];
+        if (p >= file.size()) return false;
         ++p;
+        return true;
     };
-    while (p < file.size() && file[p]) {
+    bool header_ended = false;
+    while (p < file.size()) {
+        if (!file[p]) {
+            header_ended = true;
+            break;
+        }
         std::string name, type;
-        cstr(name);
-        cstr(type);
-        if (p + 4 > file.size()) break;
+        if (!cstr(name) || !cstr(type) || p + 4 > file.size()) break;
         uint32_t size;
         memcpy(&size, &file[p], 4);
         p += 4;
+        if ((size_t)size > file.size() - p) break;   // the attribute's value must lie inside the file
         const uint8_t *v = &file[p];
         if (name == "channels") {
             size_t q = 0;
             while (q < size && v[q]) {
                 Chan c;
-                while (v[q]) c.name += (char)v[q++];
-                ++q;
+                while (q < size && v[q]) c.name += (char)v[q++];
+                ++q;   // the name's terminator
+                if (q + 16 > size) {
+                    err = "bad EXR channel list";
+                    return false;
+                }
                 int32_t t;
                 memcpy(&t, v + q, 4);
+                if (t < 0 || t > 2) {
+                    err = "bad EXR channel type";
+                    return false;
+                }
                 c.type = t;
                 q += 16;
                 chans.push_back(c);
             }
         } else if (name == "compression") {
+            if (size < 1) break;
             compression = v[0];
         } else if (name == "dataWindow") {
+            if (size < 16) break;
             int32_t b[4];
             memcpy(b, v, 16);
             xmin = b[0];
@@ -261,13 +279,18 @@ bool decode_exr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         }
         p += size;
     }
+    if (!header_ended) {
+        err = "truncated EXR header";
+        return false;
+    }
     ++p;
-    w = xmax - xmin + 1;
-    h = ymax - ymin + 1;
-    if (w <= 0 || h <= 0 || chans.empty()) {
+    const int64_t w64 = xmax - xmin + 1, h64 = ymax - ymin + 1;
+    if (w64 <= 0 || h64 <= 0 || chans.empty() || w64 > (1 << 16) || h64 > (1 << 16) || w64 * h64 > (int64_t)1 << 28) {   // the bound decode_png uses
         err = "bad EXR header";
         return false;
     }
+    w = (int)w64;
+    h = (int)h64;
     int lines_per_block = compression == 0 || compression == 2 ? 1 : compression == 3 ? 16 : 0;
     if (!lines_per_block) {
         err = "EXR compression not supported (only NONE, ZIPS, ZIP)";
@@ -276,7 +299,7 @@ bool decode_exr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     size_t bytes_per_line = 0;
     for (auto &c : chans) bytes_per_line += (size_t)w * (c.type == 1 ? 2 : 4);
     int nblocks = (h + lines_per_block - 1) / lines_per_block;
-    if (p + (size_t)nblocks * 8 > file.size()) {
+    if (p > file.size() || (size_t)nblocks * 8 > file.size() - p) {
         err = "truncated EXR";
         return false;
     }
@@ -286,19 +309,27 @@ bool decode_exr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     for (int b = 0; b < nblocks; ++b) {
         uint64_t off;
         memcpy(&off, &file[p + (size_t)b * 8], 8);
-        if (off + 8 > file.size()) {
+        if (off > file.size() || file.size() - off < 8) {
             err = "truncated EXR";
             return false;
         }
         int32_t y0, dsize;
         memcpy(&y0, &file[off], 4);
         memcpy(&dsize, &file[off + 4], 4);
-        if (off + 8 + (size_t)dsize > file.size()) {
+        if (dsize < 0 || (uint64_t)dsize > file.size() - off - 8) {
             err = "truncated EXR";
             return false;
         }
-        int lines = std::min(lines_per_block, ymax - y0 + 1);
+        if (y0 < ymin || y0 > ymax) {
+            err = "EXR block outside the data window";
+            return false;
+        }
+        int lines = (int)std::min<int64_t>(lines_per_block, ymax - y0 + 1);
         size_t raw_size = bytes_per_line * (size_t)lines;
+        if (!(compression != 0 && (size_t)dsize < raw_size) && (size_t)dsize != raw_size) {   // stored as it is: the sizes must agree
+            err = "EXR block size does not match its scan lines";
+            return false;
+        }
         const uint8_t *src = &file[off + 8];
         if (compression != 0 && (size_t)dsize < raw_size) {
             if (!zlib_inflate(src, (size_t)dsize, tmp, raw_size) || tmp.size() != raw_size) {
@@ -312,7 +343,7 @@ bool decode_exr(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
             src = block.data();
         }
         for (int l = 0; l < lines; ++l) {
-            int y = y0 - ymin + l;
+            const int y = (int)(y0 - ymin) + l;
             const uint8_t *q = src + bytes_per_line * (size_t)l;
             for (auto &c : chans) {
                 int slot = c.name == "R" ? 0 : c.name == "G" ? 1 : c.name == "B" ? 2 : c.name == "A" ? 3 : (chans.size() == 1 ? -2 : -1);

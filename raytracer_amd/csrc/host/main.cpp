@@ -24,6 +24,8 @@
 #include <thread>
 #include <vector>
 
+#include <cerrno>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "rt_host.h"
@@ -48,6 +50,23 @@ static void log_printf(const char *fmt, ...) {
         fflush(g_log);
     }
     fflush(stdout);
+}
+
+// Runs args[0] with the given arguments and waits for it; true when it exits with status 0.
+static bool run_program(const std::vector<std::string> &args) {
+    std::vector<char *> argv;
+    for (const auto &a : args) argv.push_back(const_cast<char *>(a.c_str()));
+    argv.push_back(nullptr);
+    const pid_t pid = fork();
+    if (pid < 0) return false;
+    if (pid == 0) {
+        execv(argv[0], argv.data());
+        _exit(127);
+    }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0)
+        if (errno != EINTR) return false;
+    return WIFEXITED(status) && WEXITSTATUS(status) == 0;
 }
 
 // PNG sequences `<prefix>_<digits>.png` in `folder` -> `<prefix>.mp4` through the bundled ffmpeg
@@ -76,10 +95,14 @@ static void create_videos_from_png_sequences(const std::string &folder) {
         int pad = (int)m[2].str().length();
         std::string input = (fs::path(folder) / (prefix + "_%0" + std::to_string(pad) + "d.png")).string();
         std::string output = (fs::path(folder) / (prefix + ".mp4")).string();
-        std::string cmd = ffmpeg + " -y -framerate 30 -i \"" + input +
-                          "\" -c:v libopenh264 -b:v 8M -maxrate 8M -bufsize 16M -preset slow -profile:v high -pix_fmt yuv420p \"" + output + "\"";
-        printf("Running: %s\n", cmd.c_str());
-        if (system(cmd.c_str()) != 0) {
+        // argv, not a shell line: the names come from the scene files' ImageName
+        const std::vector<std::string> args = {ffmpeg, "-y", "-framerate", "30", "-i", input, "-c:v", "libopenh264", "-b:v", "8M", "-maxrate", "8M",
+                                               "-bufsize", "16M", "-preset", "slow", "-profile:v", "high", "-pix_fmt", "yuv420p", output};
+        printf("Running:");
+        for (const auto &a : args) printf(" %s", a.c_str());
+        printf("\n");
+        fflush(stdout);
+        if (!run_program(args)) {
             fprintf(stderr, "FFmpeg execution failed\n");
             continue;
         }
@@ -194,11 +217,13 @@ private:
     }
 
     // the reference exits the process where it fails; earlier files' log lines come out first
+    // (and their images are on disk: the reference has written them by the time a later file fails)
     [[noreturn]] void fail(size_t index, int code) {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return flushed_ == index; });
         log_printf("%s", jobs_[index].log.c_str());
         fflush(stdout);
+        cv_.wait(lk, [&] { return write_queue_.empty() && writes_in_flight_ == 0; });
         _exit(code & 0xff);
     }
 
@@ -425,8 +450,19 @@ private:
                 if (write_queue_.empty()) return;
                 t = std::move(write_queue_.front());
                 write_queue_.erase(write_queue_.begin());
+                ++writes_in_flight_;
             }
             cv_.notify_all();
+            struct Done {   // runs after the file is written
+                Pipeline *p;
+                ~Done() {
+                    {
+                        std::lock_guard<std::mutex> lk(p->m_);
+                        --p->writes_in_flight_;
+                    }
+                    p->cv_.notify_all();
+                }
+            } done{this};
             const auto t_write = std::chrono::high_resolution_clock::now();
             struct Report {
                 std::chrono::high_resolution_clock::time_point t0;
@@ -453,7 +489,7 @@ private:
     std::vector<WriteTask> write_queue_;
     std::mutex m_;
     std::condition_variable cv_;
-    size_t next_load_ = 0, next_render_ = 0, flushed_ = 0;
+    size_t next_load_ = 0, next_render_ = 0, flushed_ = 0, writes_in_flight_ = 0;
     bool writers_may_stop_ = false;
 };
 

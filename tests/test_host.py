@@ -231,3 +231,18 @@ def test_png_texels_match_reference_decoder(name):
     assert got is not None, R.host_lib().rth_last_error()
     assert got.shape == want.shape
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} bytes differ"
+
+
+def test_write_outputs_follows_the_reference(tmp_path):
+    """One EXR for an .exr camera plus one PNG per tone map (src/main.cpp:561-607); a plain PNG otherwise."""
+    import raytracer_amd as R
+    from raytracer_amd import scenegen
+    from oracle_lib import Oracle
+    sc = R.Scene(scenegen.write_path_traced_scene(str(tmp_path / "s"), n=24, width=48, height=27, spp=4))
+    img, _ = Oracle(sc).render(sc.camera(0), threads=2)
+    paths = R.write_outputs(sc, 0, img, out_dir=str(tmp_path / "o"))
+    assert [os.path.basename(p) for p in paths] == ["pt1m.exr", "pt1m_phot.png"]
+    assert np.array_equal(png_pixels(paths[1]), sc.tonemap(0, 0, img)[::-1])
+    sc2 = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
+    img2, _ = Oracle(sc2).render(sc2.camera(0), threads=2)
+    assert [os.path.basename(p) for p in R.write_outputs(sc2, 0, img2, out_dir=str(tmp_path / "o"))] == ["simple.png"]
