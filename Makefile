@@ -5,7 +5,7 @@
 #   oracle/liboracle.so          CPU checker (tests only); oracle/_ref/* when the reference is present
 HIPCC ?= hipcc
 CXX ?= g++
-HOST_SRCS = $(addprefix raytracer_amd/csrc/host/,ingest.cpp ply.cpp bvh_build.cpp image_io.cpp jpeg.cpp tonemap.cpp host_api.cpp)
+HOST_SRCS = $(addprefix raytracer_amd/csrc/host/,ingest.cpp ply.cpp bvh_build.cpp image_io.cpp jpeg.cpp tonemap.cpp scene_cache.cpp host_api.cpp)
 HOST_HDRS = $(wildcard raytracer_amd/csrc/host/*.h) include/gpu_render.h include/rt_host.h
 HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-vector-combine -fPIC -std=c++17 -Iinclude -Iraytracer_amd/csrc/gpu
 

@@ -321,6 +321,7 @@ void parse_images(const Value &scene, const std::string &base_dir, HostScene &ou
         if (!img.has("_id") || !img.has("_data")) return;
         int id = int_of(img["_id"]);
         std::string full = (std::filesystem::path(base_dir) / img["_data"].str).string();
+        out.dependencies.push_back(full);
         rt_image im{};
         std::string err;
         if (!load_image_file(full, out, im, err)) {
@@ -533,6 +534,7 @@ void sphere_bounds(const rt_sphere &s, PrimBounds &b) {   // src/shapes.cpp:344-
 }  // namespace
 
 rt_scene_desc HostScene::desc() const {
+    if (mapping) return mapped_desc;
     rt_scene_desc d{};
     d.abi_version = RT_ABI_VERSION;
     d.n_triangles = (int32_t)triangles.size();
@@ -573,6 +575,11 @@ rt_scene_desc HostScene::desc() const {
 
 bool load_scene(const std::string &json_path, HostScene &out, std::string &err) {
     auto t0 = std::chrono::high_resolution_clock::now();
+    if (scene_cache_load(json_path, out)) {
+        out.ingest_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        out.bvh_ms = 0;
+        return true;
+    }
     Value doc;
     if (!rtjson::parse_file(json_path, doc, err)) return false;
     const Value &scene = doc["Scene"];
@@ -654,6 +661,7 @@ bool load_scene(const std::string &json_path, HostScene &out, std::string &err) 
         size_t first_tri = out.triangles.size();
         if (mesh["Faces"].has("_plyFile")) {
             std::string full = (std::filesystem::path(base_dir) / mesh["Faces"]["_plyFile"].str).string();
+            out.dependencies.push_back(full);
             PlyResult pr;
             if (!load_ply(full, vertices, out, smooth, pr, err)) {
                 ok = false;
@@ -909,6 +917,9 @@ bool load_scene(const std::string &json_path, HostScene &out, std::string &err) 
     auto t2 = std::chrono::high_resolution_clock::now();
     out.ingest_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     out.bvh_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    out.build_prims = {};   // only the build needed them
+    out.build_bounds = {};
+    scene_cache_store(json_path, out);
     return true;
 }
 

@@ -2,6 +2,7 @@
 // plus the per-camera output description (image name, tone-map operators) that stays on the host.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,8 @@ struct HostCamera {
 struct PrimBounds {       // world-space padded box of one (shape, placement) pair
     float bmin[3], bmax[3];
 };
+
+struct SceneMapping;   // a scene cache file mapped into memory (scene_cache.cpp)
 
 struct HostScene {
     std::vector<rt_triangle> triangles;
@@ -58,12 +61,23 @@ struct HostScene {
     double ingest_ms = 0, bvh_ms = 0;
     std::vector<std::string> warnings;
 
+    // files the scene pulled in (PLY meshes, images), for the scene cache
+    std::vector<std::string> dependencies;
+    // A scene that came out of the scene cache keeps its arrays in the mapped file instead of the vectors above: `mapping`
+    // holds the file, `mapped_desc` points into it.
+    std::shared_ptr<SceneMapping> mapping;
+    rt_scene_desc mapped_desc{};
+
     rt_scene_desc desc() const;
 };
 
 // Parses a scene file of the reference's JSON dialect (src/parser.cpp) including PLY meshes
 // (src/ply_loader.cpp) and builds the BVH.  Returns false and fills `err` on failure.
 bool load_scene(const std::string &json_path, HostScene &out, std::string &err);
+
+// The scene cache (RT_SCENE_CACHE=<directory>): load_scene tries scene_cache_load first and stores what it built.
+bool scene_cache_load(const std::string &json_path, HostScene &out);
+void scene_cache_store(const std::string &json_path, const HostScene &scene);
 
 // SAH BVH build over build_prims/build_bounds (reference src/bvh.cpp:41-344).
 void build_bvh(HostScene &scene);

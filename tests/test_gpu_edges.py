@@ -118,6 +118,20 @@ def test_recursion_depth_beyond_sixty_four(scene_dir, tmp_path):
     assert st.secondary_rays > 0
 
 
+def test_scene_from_the_cache_renders_the_same(scene_dir, tmp_path, monkeypatch):
+    """A scene mapped from its cache file (RT_SCENE_CACHE) goes to the device straight from the mapping."""
+    path = GS.SCENES["textured"][0](scene_dir)
+    monkeypatch.delenv("RT_SCENE_CACHE", raising=False)
+    sc = R.Scene(path)
+    fresh, _ = R.Renderer(sc).render(sc.camera(0))
+    monkeypatch.setenv("RT_SCENE_CACHE", str(tmp_path / "cache"))
+    R.Scene(path)
+    cached_scene = R.Scene(path)
+    assert cached_scene.timings()["bvh_ms"] == 0
+    cached, _ = R.Renderer(cached_scene).render(cached_scene.camera(0))
+    assert np.abs(cached - fresh).max() <= 1e-5 * max(1.0, float(fresh.max()))
+
+
 def test_rejected_descriptions():
     g = R.gpu_lib()
     sc = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
