@@ -274,14 +274,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
     }
     __syncthreads();
     const int shard = blockIdx.x % N_SHARDS;
-    unsigned *ctr = counter_of(W, ANY ? Q_SHADOW : Q_PATH, gen, shard);
-    const unsigned room = ANY ? W.shadow_shard_entries : W.shard_entries;
+    // any hit, `whitted` = 1: the shading kernel wrote one shadow ray per vertex, ray i for vertex i, and counted the vertices
+    unsigned *ctr = counter_of(W, ANY ? (whitted ? Q_VERTEX : Q_SHADOW) : Q_PATH, gen, shard);
+    const unsigned room = ANY ? (whitted ? min(W.shard_entries, W.shadow_shard_entries) : W.shadow_shard_entries) : W.shard_entries;
     unsigned count = ctr[0];
     if (count > room) count = room;
     // next unclaimed entry of this shard; shares the append counter's line, zeroed with it (word 2 of a shadow line
     // counts the light-sample records)
     unsigned *fetch = ctr + 1;
-    const unsigned base_idx = shard * room;
+    const unsigned base_idx = shard * (ANY ? W.shadow_shard_entries : W.shard_entries);
     const PathQueue &Q = W.q[gen & 1];
     const float eps = ANY ? S.seps : S.ieps;
     const unsigned lane = threadIdx.x & 63;
@@ -486,7 +487,7 @@ template <bool PT>
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, int emitter_rays, unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries;
     unsigned count = *counter_of(W, Q_PATH, gen, shard);
@@ -757,6 +758,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                     W.vtx[gen & 1].ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
                     W.vtx[gen & 1].weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
                     W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
+                    if (emitter_rays) {
+                        // The scene's only light is one sphere emitter, whose samples share one shadow ray per vertex (see
+                        // light_setup_kernel): the ray is written here, ray i for vertex i, and no set-up pass runs.
+                        V ldir;
+                        float dist, d2;
+                        sphere_light_geometry(S.spheres[S.lights[0].sphere], v_p, ldir, dist, d2);
+                        const V so = add(v_p, scl(ldir, S.seps));
+                        const unsigned ri = shard * W.shadow_shard_entries + vl;
+                        if (vl < W.shadow_shard_entries) {
+                            ++c.traced;
+                            W.shadow[gen & 1].o_dist[ri] = make_float4(so.x, so.y, so.z, dist);
+                            W.shadow[gen & 1].d_time[ri] = make_float4(ldir.x, ldir.y, ldir.z, time);
+                        } else {
+                            *W.overflow = 1u;
+                        }
+                    }
                 }
             }
         }
@@ -978,7 +995,9 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
         if (defer != 0 && L.type == RT_LIGHT_SPHERE) {
             const rt_sphere &sph = S.spheres[L.sphere];
             bool lit = false;
-            if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
+            if (active && defer == 2) {   // the shading kernel wrote the rays: ray i for vertex i
+                lit = Q.vis[shadow_base + vl] != 0.f;
+            } else if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
                 const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
                 lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3]) + rec_lane] != 0.f;
             }
@@ -1089,7 +1108,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const float4 af = B.amb_first[v], w = B.weight[v];
         unsigned long long have = has_records ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
         const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
-        if (!room) have = 0;
+        if (!room) {   // (light_setup_kernel has reported it; with the rays written by the shading kernel this is where it shows)
+            have = 0;
+            *W.overflow = 1u;
+        }
         bool full = valid && have != 0;
         if (defer != 0 && room) {   // `defer`: the pass holds deferred lights; is one of them visible from the vertex?
             for (int kl = 0, kend; kl < kn; kl = kend) {
@@ -1097,6 +1119,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
                 const rt_light &L = S.lights[li];
                 kend = min(kn, light_of[k_total + li] + L.samples - k0);
                 if (L.type != RT_LIGHT_SPHERE) continue;
+                if (defer == 2) {
+                    if (valid && W.shadow[gen & 1].vis[shadow_base + vl] != 0.f) full = true;
+                    continue;
+                }
                 const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
                 const unsigned first_ray = __float_as_uint(((const float *)&W.shadow[gen & 1].fd_ray[ri])[3]);
                 if (valid && W.shadow[gen & 1].vis[first_ray + lane] != 0.f) full = true;
@@ -1238,6 +1264,7 @@ struct rt_scene {
     int slot_table = -1;              // offset of the deferred-mode slot table in light_of
     std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
+    bool single_sphere_emitter = false;   // the scene's lights are exactly one sphere emitter
     // this rank's tiles of a frame that is split over several ranks (see shard_owner)
     int *owned_tiles = nullptr;       // device copy of the list
     size_t owned_room = 0;
@@ -1823,6 +1850,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         }
         keep(s->light_of);
         for (int i = 0; i < d->n_materials; ++i) s->has_dielectric |= d->materials[i].type == RT_MAT_DIELECTRIC;
+        s->single_sphere_emitter = d->n_lights == 1 && d->lights[0].type == RT_LIGHT_SPHERE && d->lights[0].samples <= 64;
     }
     *out = s;
     return 0;
@@ -1996,6 +2024,10 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     const int share_rays = (!(share_env && atoi(share_env) == 0) && !s->counters) ? 1 : 0;
     const unsigned slots_per_vertex = (unsigned)(share_rays ? s->k_pad_deferred : s->k_pad);   // shadow slots of a vertex in one pass
     const int slot_table = share_rays ? s->slot_table : -1;
+    // With one sphere emitter as the only light, the shading kernel writes the emitter's one shadow ray per vertex itself
+    // (RT_FUSED_EMITTER_RAYS=0: through light_setup_kernel as for any other scene, for A/B timing).
+    static const bool fuse_allowed = !(getenv("RT_FUSED_EMITTER_RAYS") && atoi(getenv("RT_FUSED_EMITTER_RAYS")) == 0);
+    const int emitter_rays = share_rays && s->single_sphere_emitter && fuse_allowed ? 1 : 0;
     if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex,
                                   1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024, std::max(1, (int)ceilf(s->dev.max_depth) + 2)))
         return rc;
@@ -2059,15 +2091,19 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             {
                 LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
                 if (pt)
-                    hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+                    hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
                 else
-                    hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, s->stats);
+                    hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
             }
             HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
             HIP_OK(hipStreamWaitEvent(lighting, s->shaded[gen], 0));
             const int n_pass = (s->k_total + 63) / 64;
-            for (int pass = 0; pass < n_pass; ++pass) {
-                if (pass > 0)
+            if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
+                launch_trace(s, lighting, true, grid, gen, 1);
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, 2, s->stats);
+            }
+            for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {                if (pass > 0)
                     HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                           N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                 {

@@ -26,7 +26,9 @@ def test_exact_scene_against_reference(name, scene_dir, repo_root):
     assert np.mean(np.abs(t[both] - ref_t[both]) > 2e-4 * np.maximum(1.0, ref_t[both])) <= 1e-3
     img, _ = ren.render(cam)
     err = (np.abs(img - g["hdr"]) / np.maximum(np.abs(g["hdr"]), 1.0 / 255.0)).max(axis=2)
-    assert (err > 2e-3).mean() <= 1e-3, f"{(err > 2e-3).sum()} pixels differ from the reference image (max {err.max():.3g})"
+    # 1e-3 relative on 99.99 % of the pixels; these fixtures have 4 K to 58 K pixels, so the remainder is the 1 to 3
+    # silhouette / texture-seam pixels measured (the reference's approximate reciprocal square root moves a hit across an edge)
+    assert (err > 1e-3).sum() <= max(3, 1e-4 * err.size), f"{(err > 1e-3).sum()} pixels differ from the reference image (max {err.max():.3g})"
 
 
 @pytest.mark.parametrize("name", STOCHASTIC)

@@ -5,7 +5,8 @@ Bars (the reference's own builds disagree with each other on ~1e-5 of primary-hi
 -ffast-math and its approximate rsqrt, so exact equality with the reference is not attainable):
   * primary-hit (shape, instance id): mismatch fraction <= 1e-4 of pixels at these fixture resolutions (silhouette
     pixels only; at 1920x1080 on the 70K-triangle mesh the measured mismatch is 19 of 2,073,600 = 9.2e-6)
-  * deterministic images: |d| <= 2e-3 * max(|ref|, 1/255) on >= 99.9 % of pixels
+  * deterministic images: |d| <= 1e-3 * max(|ref|, 1/255) on >= 99.99 % of pixels, at least 3 pixels allowed (measured: 0 to 3
+    pixels per fixture exceed it, all on silhouettes and texture seams)
   * stochastic images (the reference's random numbers cannot be seeded): per-pixel difference within 6 combined
     standard errors or 5 % for >= 99.8 % of values, and image means within 2 %
 """
@@ -84,7 +85,9 @@ def test_exact_scene_against_reference(name, scene_dir, repo_root):
     assert np.mean(np.abs(t[both] - ref_t[both]) > 2e-4 * np.maximum(1.0, ref_t[both])) <= 1e-3   # grazing sphere hits excepted
     img, _ = orc.render(cam)
     err = (np.abs(img - g["hdr"]) / np.maximum(np.abs(g["hdr"]), 1.0 / 255.0)).max(axis=2)
-    assert (err > 2e-3).mean() <= 1e-3, f"{(err > 2e-3).sum()} pixels differ from the reference image (max {err.max():.3g})"
+    # 1e-3 relative on 99.99 % of the pixels; these fixtures have 4 K to 58 K pixels, so the remainder is the 1 to 3
+    # silhouette / texture-seam pixels measured (the reference's approximate reciprocal square root moves a hit across an edge)
+    assert (err > 1e-3).sum() <= max(3, 1e-4 * err.size), f"{(err > 1e-3).sum()} pixels differ from the reference image (max {err.max():.3g})"
 
 
 def test_simple_scene_known_answers(repo_root):
