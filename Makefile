@@ -11,8 +11,16 @@ HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-roun
 
 all: raytracer_amd/librt_gpu.so raytracer_amd/librt_host.so raytracer oracle
 
-raytracer_amd/librt_gpu.so: raytracer_amd/csrc/gpu/render.hip $(wildcard raytracer_amd/csrc/gpu/*.h) include/gpu_render.h
-	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+# two translation units: the render path, and the device BVH builder (it pulls in the radix sort of hipCUB, slow to compile)
+GPU_HDRS = $(wildcard raytracer_amd/csrc/gpu/*.h) include/gpu_render.h
+build/render.o: raytracer_amd/csrc/gpu/render.hip $(GPU_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/bvh_gpu.o: raytracer_amd/csrc/gpu/bvh_gpu.hip raytracer_amd/csrc/gpu/rt_bvh_gpu.h raytracer_amd/csrc/gpu/rt_device.h raytracer_amd/csrc/gpu/rt_math.h include/gpu_render.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+raytracer_amd/librt_gpu.so: build/render.o build/bvh_gpu.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
 raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) -std=c++17 -O2 -fPIC -shared -Wall -Iinclude -Iraytracer_amd/csrc/host $(HOST_SRCS) -lz -o $@

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* ---- enums (values follow the reference's enum order) ---------------------------------------- */
 enum { RT_MAT_REGULAR = 0, RT_MAT_MIRROR = 1, RT_MAT_CONDUCTOR = 2, RT_MAT_DIELECTRIC = 3 }; /* src/shapes.h:20-26 */
@@ -190,6 +190,12 @@ typedef struct rt_scene_desc {
 
     int32_t n_bvh_nodes;   const rt_bvh_node *bvh_nodes;
     int32_t n_bvh_prims;   const rt_bvh_prim *bvh_prims;
+    /* A scene may come without a tree: n_bvh_nodes = 0, bvh_prims = every (shape, placement) pair in any order and
+     * bvh_prim_bounds = their world-space boxes (6 floats each: min xyz, max xyz; the padded boxes the reference's builder
+     * starts from, src/bvh.cpp:55-73).  The library then builds a tree on the device (Morton order, one leaf per pair).
+     * Such a tree is not the reference's: the closest hit is the same, hits at exactly equal distance may resolve to
+     * another primitive.  NULL when the tree is given. */
+    const float *bvh_prim_bounds;
 
     float intersection_epsilon;   /* src/parser.cpp:1239-1244 */
     float shadow_ray_epsilon;     /* src/parser.cpp:1246-1251 */

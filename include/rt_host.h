@@ -25,6 +25,9 @@ const char *rth_scene_image_name(const rth_scene *s, int32_t index);
 int32_t rth_scene_tonemap_count(const rth_scene *s, int32_t camera);
 /* The file-name extension of tone map `index` of `camera` (the scene file's Tonemap.Extension, e.g. "_phot.png"). */
 const char *rth_scene_tonemap_extension(const rth_scene *s, int32_t camera, int32_t index);
+/* Builds the SAH tree of a scene that was loaded without one (RT_GPU_BVH=1 leaves the tree to the rendering core, which
+ * builds it on the device); no-op when the scene has its tree.  rth_scene_desc changes with it. */
+void rth_scene_build_bvh(rth_scene *s);
 /* ingest and BVH-build wall time in milliseconds */
 void rth_scene_timings(const rth_scene *s, double *ingest_ms, double *bvh_ms);
 void rth_scene_free(rth_scene *s);

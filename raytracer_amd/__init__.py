@@ -42,6 +42,7 @@ def host_lib():
         h.rth_scene_tonemap_count.argtypes = [C.c_void_p, C.c_int32]
         h.rth_scene_tonemap_extension.restype = C.c_char_p
         h.rth_scene_tonemap_extension.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        h.rth_scene_build_bvh.argtypes = [C.c_void_p]
         h.rth_scene_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         h.rth_scene_free.argtypes = [C.c_void_p]
         h.rth_tonemap.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p,
@@ -133,6 +134,11 @@ class Scene:
         if self._h.rth_scene_tonemap_apply(self._ptr, camera, index, hdr.ctypes.data, out.ctypes.data) != 0:
             raise RaytracerError("bad tonemap index")
         return out
+
+    def build_bvh(self):
+        """Builds the host's SAH tree of a scene that was loaded without one (RT_GPU_BVH=1)."""
+        self._h.rth_scene_build_bvh(self._ptr)
+        self.desc = self._h.rth_scene_desc(self._ptr).contents
 
     def timings(self):
         a, b = C.c_double(), C.c_double()

@@ -71,6 +71,7 @@ class SceneDesc(C.Structure):
         ("n_lights", i32), ("lights", C.POINTER(Light)),
         ("n_bvh_nodes", i32), ("bvh_nodes", C.POINTER(BvhNode)),
         ("n_bvh_prims", i32), ("bvh_prims", C.POINTER(BvhPrim)),
+        ("bvh_prim_bounds", C.POINTER(f32)),
         ("intersection_epsilon", f32), ("shadow_ray_epsilon", f32), ("max_depth", f32),
         ("ambient_light", F3), ("background_color", F3), ("background_texture", i32), ("is_probe", i32),
     ]

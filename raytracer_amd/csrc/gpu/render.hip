@@ -29,6 +29,7 @@
 #include "rt_math.h"
 #include "rt_device.h"
 #include "rt_wide.h"
+#include "rt_bvh_gpu.h"
 
 using namespace rt;
 
@@ -1596,6 +1597,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         return 3;
     }
 
+    const bool build_tree = d->n_bvh_nodes == 0 && d->n_bvh_prims > 0;   // the scene comes without a tree: it is built on the device
+    if (build_tree && !d->bvh_prim_bounds) {
+        g_error = "rt_scene_create: a scene without BVH nodes needs bvh_prim_bounds";
+        return 3;
+    }
     rt_scene *s = new rt_scene();
     if (hipError_t e = hipGetDevice(&s->device); e != hipSuccess) {
         g_error = std::string("hipGetDevice: ") + hipGetErrorString(e);
@@ -1667,14 +1673,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         if (d->n_bvh_nodes > 0) root_ref = ref_of(0);
     }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
-    std::vector<float4> prims((size_t)d->n_bvh_prims * PRIM_STRIDE);
-    std::vector<int4> prim_meta((size_t)d->n_bvh_prims * 2, make_int4(0, 0, 0, 0));
+    const int n_host_entries = build_tree ? 0 : d->n_bvh_prims;   // (a tree built on the device makes its entries there)
+    std::vector<float4> prims((size_t)n_host_entries * PRIM_STRIDE);
+    std::vector<int4> prim_meta((size_t)n_host_entries * 2, make_int4(0, 0, 0, 0));
     auto as_float = [](int v) {
         float f;
         memcpy(&f, &v, 4);
         return f;
     };
-    for (int i = 0; i < d->n_bvh_prims; ++i) {
+    for (int i = 0; i < n_host_entries; ++i) {
         const rt_bvh_prim &p = d->bvh_prims[i];
         if (p.shape < d->n_triangles) {
             const rt_triangle &t = d->triangles[p.shape];
@@ -1720,8 +1727,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         inst[4 * i + 3] = make_float4(in.motionblur[0], in.motionblur[1], in.motionblur[2], as_float(flags));
     }
     // flat normals: normalize(cross(e1s, e2s)) (src/shapes.cpp:26-33), evaluated in the same order as on the device
-    std::vector<float> flat((size_t)d->n_triangles * 3);
-    for (int i = 0; i < d->n_triangles; ++i) {
+    std::vector<float> flat(build_tree ? 0 : (size_t)d->n_triangles * 3);
+    for (int i = 0; i < d->n_triangles && !build_tree; ++i) {
         const rt_triangle &t = d->triangles[i];
         float e1[3], e2[3];
         for (int a = 0; a < 3; ++a) {
@@ -1735,7 +1742,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         for (int a = 0; a < 3; ++a) flat[3 * i + a] = len2 > 1e-12f ? n[a] * inv : 0.0f;
     }
 
-    for (int i = 0; i < d->n_bvh_prims; ++i) {   // the face normal travels with the entry's shading record
+    for (int i = 0; i < n_host_entries; ++i) {   // the face normal travels with the entry's shading record
         const rt_bvh_prim &p = d->bvh_prims[i];
         if (p.shape >= d->n_triangles) continue;
         int bits[3];
@@ -1756,12 +1763,35 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         D.field = dp_;                                                                \
         keep(tmp_);                                                                   \
     } while (0)
-    UP(nodes, nodes.data(), nodes.size());
-    UP(prims, prims.data(), prims.size());
-    UP(prim_meta, prim_meta.data(), prim_meta.size());
     UP(inst, inst.data(), inst.size());
     UP(instances, d->instances, d->n_instances);
     UP(triangles, d->triangles, d->n_triangles);
+    DeviceBvh built;
+    if (build_tree) {
+        // the walk's stack holds LDS_STACK + SPILL_STACK far children, one per level
+        if (int rc = build_bvh_on_device(d->bvh_prims, d->bvh_prim_bounds, d->n_bvh_prims, D.triangles, d->n_triangles, D.instances, LDS_STACK + SPILL_STACK - 1, built, g_error)) {
+            rt_scene_destroy(s);
+            return rc;
+        }
+        D.nodes = built.nodes, D.prims = built.prims, D.prim_meta = built.prim_meta;
+        for (void *p : {(void *)built.nodes, (void *)built.prims, (void *)built.prim_meta})
+            if (p) keep(p);
+        if (!built.nodes) {   // (pointers stay valid for an empty array, as upload() keeps them)
+            float4 *dummy = nullptr;
+            if (upload<float4>(nullptr, 0, &dummy)) {
+                rt_scene_destroy(s);
+                return 10;
+            }
+            D.nodes = dummy;
+            keep(dummy);
+        }
+        root_ref = built.root_ref;
+        s->dev.n_top = 0;   // the records are not in breadth-first order: no top of the tree in LDS
+    } else {
+        UP(nodes, nodes.data(), nodes.size());
+        UP(prims, prims.data(), prims.size());
+        UP(prim_meta, prim_meta.data(), prim_meta.size());
+    }
     UP(spheres, d->spheres, d->n_spheres);
     UP(planes, d->planes, d->n_planes);
     UP(materials, d->materials, d->n_materials);
@@ -1776,8 +1806,12 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     D.n_spheres = d->n_spheres;
     D.n_planes = d->n_planes;
     D.n_lights = d->n_lights;
-    D.n_nodes = d->n_bvh_nodes;
+    D.n_nodes = build_tree ? 2 * d->n_bvh_prims - 1 : d->n_bvh_nodes;
     D.root_ref = root_ref;
+    if (build_tree) {
+        memcpy(D.root_min, built.root_min, sizeof D.root_min);
+        memcpy(D.root_max, built.root_max, sizeof D.root_max);
+    }
     {
         const char *e = getenv("RT_WIDE_NODES");
         const int mode = e ? atoi(e) : -1;

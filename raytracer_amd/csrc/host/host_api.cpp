@@ -36,6 +36,10 @@ int rth_scene_load(const char *json_path, rth_scene **out) {
 }
 
 const rt_scene_desc *rth_scene_desc(const rth_scene *s) { return &s->desc; }
+void rth_scene_build_bvh(rth_scene *s) {
+    rth::ensure_host_bvh(s->scene);
+    s->desc = s->scene.desc();
+}
 int32_t rth_scene_camera_count(const rth_scene *s) { return (int32_t)s->scene.cameras.size(); }
 const rt_camera_desc *rth_scene_camera(const rth_scene *s, int32_t i) {
     if (i < 0 || i >= (int32_t)s->scene.cameras.size()) return nullptr;

@@ -563,6 +563,13 @@ rt_scene_desc HostScene::desc() const {
     d.bvh_nodes = bvh_nodes.data();
     d.n_bvh_prims = (int32_t)bvh_prims.size();
     d.bvh_prims = bvh_prims.data();
+    d.bvh_prim_bounds = nullptr;
+    if (bvh_nodes.empty() && !build_prims.empty()) {   // no tree built here: the rendering core builds one on the device
+        static_assert(sizeof(PrimBounds) == 6 * sizeof(float), "a box is six floats");
+        d.n_bvh_prims = (int32_t)build_prims.size();
+        d.bvh_prims = build_prims.data();
+        d.bvh_prim_bounds = &build_bounds[0].bmin[0];
+    }
     d.intersection_epsilon = intersection_epsilon;
     d.shadow_ray_epsilon = shadow_ray_epsilon;
     d.max_depth = max_depth;
@@ -571,6 +578,15 @@ rt_scene_desc HostScene::desc() const {
     d.background_texture = background_texture;
     d.is_probe = is_probe;
     return d;
+}
+
+void ensure_host_bvh(HostScene &scene) {
+    if (scene.mapping || !scene.bvh_nodes.empty() || scene.build_prims.empty()) return;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    build_bvh(scene);
+    scene.bvh_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    scene.build_prims = {};   // only the build needed them
+    scene.build_bounds = {};
 }
 
 bool load_scene(const std::string &json_path, HostScene &out, std::string &err) {
@@ -913,12 +929,14 @@ bool load_scene(const std::string &json_path, HostScene &out, std::string &err) 
         out.build_bounds.push_back(b);
     }
     auto t1 = std::chrono::high_resolution_clock::now();
-    build_bvh(out);
-    auto t2 = std::chrono::high_resolution_clock::now();
     out.ingest_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    out.bvh_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    out.build_prims = {};   // only the build needed them
-    out.build_bounds = {};
+    // RT_GPU_BVH=1: no tree is built here; the scene goes to the rendering core with its primitives' boxes and gets a tree
+    // built on the device (faster to make, not the reference's: see rt_scene_desc::bvh_prim_bounds)
+    if (const char *e = getenv("RT_GPU_BVH"); e && atoi(e) != 0) {
+        out.bvh_ms = 0;
+        return true;
+    }
+    ensure_host_bvh(out);
     scene_cache_store(json_path, out);
     return true;
 }

@@ -324,7 +324,13 @@ private:
                 }
                 if (mine) rt_scene_destroy(mine);
             });
-        const bool created = rt_scene_create(&desc, &gpu) == 0;
+        bool created = rt_scene_create(&desc, &gpu) == 0;
+        if (!created && n_ranks == 1 && desc.n_bvh_nodes == 0 && desc.n_bvh_prims > 0) {
+            // RT_GPU_BVH=1 and the device builder declined the scene (a tree deeper than the walk's stack): the host's tree
+            rth::ensure_host_bvh(job.scene);
+            desc = job.scene.desc();
+            created = rt_scene_create(&desc, &gpu) == 0;
+        }
         {
             std::unique_lock<std::mutex> lk(team.m);
             if (!created) {

@@ -81,6 +81,8 @@ void scene_cache_store(const std::string &json_path, const HostScene &scene);
 
 // SAH BVH build over build_prims/build_bounds (reference src/bvh.cpp:41-344).
 void build_bvh(HostScene &scene);
+// Builds the tree of a scene that was loaded without one (RT_GPU_BVH=1); no-op otherwise.
+void ensure_host_bvh(HostScene &scene);
 
 // PLY reader (reference src/ply_loader.cpp:63-433).  Appends vertices to `vertices` and
 // triangles to scene.triangles.

@@ -67,7 +67,7 @@ def test_missing_gpu_library_fails_loudly(monkeypatch, tmp_path):
 def test_ingest_simple_scene():
     sc = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
     d = sc.desc
-    assert sc.n_cameras == 1 and d.abi_version == 2
+    assert sc.n_cameras == 1 and d.abi_version == 3
     cam = sc.camera(0)
     assert (cam.resx, cam.resy, cam.num_samples) == (64, 64, 1)
     assert d.n_bvh_prims == d.n_triangles + d.n_spheres and d.n_bvh_nodes >= 1

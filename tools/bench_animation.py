@@ -4,7 +4,7 @@ import json, os, shutil, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracer_amd import scenegen
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 120
 work = tempfile.mkdtemp(prefix="rt_anim_")
 frames = os.path.join(work, "frames")
 base = scenegen.write_mesh_scene(frames, name="anim_0000", n=188, width=1920, height=1080)
@@ -16,13 +16,18 @@ for k in range(n):
     cam["Position"] = f"{3.2 * math.sin(a):.5f} 0.5 {3.2 * math.cos(a):.5f}"
     cam["ImageName"] = f"anim_{k:04d}.png"
     json.dump(doc, open(os.path.join(frames, f"anim_{k:04d}.json"), "w"))
-for label, exe in (("this repository", os.path.join(ROOT, "raytracer")), ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"))):
+runs = [("this repository", os.path.join(ROOT, "raytracer"), {}),
+        ("this repository, trees built on the device (RT_GPU_BVH=1)", os.path.join(ROOT, "raytracer"), {"RT_GPU_BVH": "1"}),
+        ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"), {})]
+if "--no-reference" in sys.argv:
+    runs.pop()
+for k, (label, exe, env) in enumerate(runs):
     if not os.path.exists(exe):
         continue
-    cwd = os.path.join(work, label.split()[0])
+    cwd = os.path.join(work, f"run{k}")
     os.makedirs(cwd)
     t0 = time.perf_counter()
-    r = subprocess.run([exe, frames], cwd=cwd, capture_output=True, text=True)
+    r = subprocess.run([exe, frames], cwd=cwd, capture_output=True, text=True, env=dict(os.environ, **env))
     dt = time.perf_counter() - t0
     done = sum(1 for f in os.listdir(os.path.join(cwd, "outputs")) if f.endswith(".png"))
     print(f"{label}: {n} frames in {dt:.2f} s = {n / dt:.1f} frames/s ({done} PNGs written, exit {r.returncode})")
