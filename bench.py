@@ -247,14 +247,31 @@ def main():
     # full-frame device framebuffer on rank 0 (torch is used for device memory, the barrier and the timing reductions only)
     fb = torch.zeros((cam.resy, cam.resx, 3), dtype=torch.float32, device="cuda")
     comm = None
+    gather = "none"
     if world > 1:   # the library's communicator: tiles are rendered per rank and gathered on rank 0 over RCCL
-        comm = R.Comm.init_rank(sharding.exchange_unique_id(rank, world), rank, world)
+        gather = "packed tiles to rank 0, library RCCL send/recv"
+        try:
+            comm = R.Comm.init_rank(sharding.exchange_unique_id(rank, world), rank, world)
+        except Exception as e:   # said aloud, and in the line: the frames are then summed by torch.distributed instead
+            sys.stderr.write(f"bench.py rank {rank}: library communicator unavailable ({e}); gathering with torch.distributed\n")
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            gather = "full frames summed on rank 0, torch.distributed reduce (library communicator unavailable)"
 
     def step():
-        if comm is None:
+        if world == 1:
             _, st = ren.render(cam, out=fb.data_ptr())
-        else:
+        elif comm is not None:
             _, st = ren.render_gather(comm, cam, out=fb.data_ptr())
+        else:   # every rank's tiles at their frame positions in a zeroed frame; the sum on rank 0 is the image
+            fb.zero_()
+            torch.cuda.synchronize()
+            _, st = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
+            dist.reduce(fb if args.backend == "nccl" else fb.cpu(), dst=0, op=dist.ReduceOp.SUM)
         return st
 
     def sync():
@@ -357,7 +374,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "resolution": f"{cam.resx}x{cam.resy}", "spp": cam.num_samples,
                        "triangles": sc.desc.n_triangles, "bvh_nodes": sc.desc.n_bvh_nodes,
-                       "renderer": "path tracing" if cam.path_tracing else "whitted", "sharding": f"tiles32/{world}"},
+                       "renderer": "path tracing" if cam.path_tracing else "whitted", "sharding": f"tiles32/{world}", "gather": gather},
             "ray_accounting": "value counts the BVH traversals run in the timed frames (camera and bounce paths + shadow rays traced; light "
                               "samples of a shading point whose shadow rays are identical bit for bit share one).  "
                               "value_reference_equivalent counts the rays the reference's algorithm casts for the same image (oracle "
