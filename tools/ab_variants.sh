@@ -17,7 +17,8 @@ ren.render(cam)
 ren.set_profiling(True)
 img, st = ren.render(cam)
 kt = ren.kernel_times()
-print("frame kernel_ms %.1f" % st.kernel_ms, {k: round(v[1], 1) for k, v in kt.items()})
+import hashlib
+print("frame kernel_ms %.1f" % st.kernel_ms, {k: round(v[1], 1) for k, v in kt.items()}, "image sha", hashlib.sha256(img.tobytes()).hexdigest()[:12])
 ' || exit 1
 done
 cp /tmp/librt_gpu_orig.so raytracer_amd/librt_gpu.so
