@@ -225,6 +225,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering core has no CPU fallback")
+    # (modulo: a rehearsal of several ranks on a box with fewer GPUs, --backend gloo, shares devices; a node has one per rank)
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -271,7 +273,13 @@ def main():
             fb.zero_()
             torch.cuda.synchronize()
             _, st = ren.render(cam, out=fb.data_ptr(), rank=rank, world=world)
-            dist.reduce(fb if args.backend == "nccl" else fb.cpu(), dst=0, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                host = fb.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    fb.copy_(host)
         return st
 
     def sync():
