@@ -522,10 +522,18 @@ int main(int argc, char **argv) {
         log_printf("Invalid thread count\n");
         return -1;
     }
-    // RT_GPU=<index> renders on that device; otherwise the files of a directory are spread over every visible GPU
+    // RT_GPU=<index> renders on that device, RT_GPU=<a>,<b>,... with one render thread per entry (a device named twice
+    // gets two threads: the dispatcher of several GPUs rehearsed on one); otherwise the files of a directory are spread
+    // over every visible GPU
     std::vector<int> gpus;
     if (const char *dev = getenv("RT_GPU")) {
-        gpus.push_back(atoi(dev));
+        for (const char *p = dev; *p;) {
+            gpus.push_back(atoi(p));
+            const char *comma = strchr(p, ',');
+            if (!comma) break;
+            p = comma + 1;
+        }
+        if (gpus.empty()) gpus.push_back(0);
     } else {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count < 1) count = 1;   // the first HIP call of the render thread reports the error

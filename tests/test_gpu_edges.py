@@ -200,10 +200,12 @@ def test_command_line_end_to_end(tmp_path, scene_dir):
     assert np.array_equal(png_pixels(str(tmp_path / "outputs" / "envmap_aces.png")), R.gpu_tonemap(frame, 2, 0.5, 0.0, 1.0, 1.8)[::-1])
 
 
-def test_command_line_directory_of_frames(tmp_path):
+@pytest.mark.parametrize("render_threads", ["", "0,0,0"])
+def test_command_line_directory_of_frames(tmp_path, render_threads):
     """A directory of scene files (an animation: one JSON per frame) goes through the loader / render / writer
     pipeline; every frame's image is written and equals a render through the ABI, and each file's log block stays
-    in one piece."""
+    in one piece.  With RT_GPU=0,0,0 three render threads take the frames in turn, as on a node with three GPUs (here all
+    on device 0): same images, same log order."""
     import subprocess
     from test_host import png_pixels
     frames = tmp_path / "frames"
@@ -215,7 +217,10 @@ def test_command_line_directory_of_frames(tmp_path):
             cam["Position"] = f"{0.05 * k} 0 0"
             cam["ImageName"] = f"anim_{k:04d}.png"
         patched(os.path.join(ROOT, "scenes", "simple.json"), str(frames / f"anim_{k:04d}.json"), edit)
-    r = subprocess.run([os.path.join(ROOT, "raytracer"), str(frames)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if render_threads:
+        env["RT_GPU"] = render_threads
+    r = subprocess.run([os.path.join(ROOT, "raytracer"), str(frames)], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert sum("rendering done:" in l for l in lines) == n
@@ -224,7 +229,7 @@ def test_command_line_directory_of_frames(tmp_path):
     for a, b in zip(starts, starts[1:] + [len(lines)]):            # one "started" and one "done" per block
         block = lines[a:b]
         assert sum(l.endswith(".png started") for l in block) == 1 and sum("rendering done:" in l for l in block) == 1
-    for k in (0, n // 2, n - 1):
+    for k in (0, n // 2, n - 1) if not render_threads else range(n):
         sc = R.Scene(str(frames / f"anim_{k:04d}.json"))
         img, _ = R.Renderer(sc).render(sc.camera(0))
         assert np.array_equal(png_pixels(str(tmp_path / "outputs" / f"anim_{k:04d}.png")), R.gpu_quantize_ldr(img)[::-1])
