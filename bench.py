@@ -35,7 +35,7 @@ L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the eight XCDs
 WORKLOADS = {
     # config 4: 1M+ triangle mesh, path traced, 4K, 256 spp
     "pt1m_4k_256spp": dict(kind="pt", n=710, width=3840, height=2160, spp=256, max_depth=4,
-                           cpu=dict(width=480, height=270, spp=16)),
+                           cpu=dict(width=960, height=540, spp=16)),
     # config 3: textured multi-object scene, two area lights, glossy mirror, depth of field, 64 spp (Whitted shading)
     "textured_1080p_64spp": dict(kind="textured", n=188, width=1920, height=1080, spp=64, cpu=dict(width=480, height=270, spp=16)),
     # config 2: ~70K triangle mesh, Blinn-Phong + shadows, 1080p, 1 spp
