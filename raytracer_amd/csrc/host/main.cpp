@@ -171,8 +171,11 @@ public:
 
     void run() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), std::max(1u, std::min(4u, hw / 2)));
-        const unsigned n_write = std::max(1u, std::min(4u, hw / 2));
+        // per render thread (one per GPU) up to four loaders and four writers: a 1080p frame of a light scene takes 4 ms to
+        // render, 4-10 ms to parse and 16 ms to encode as PNG, so eight GPUs need eight times the helpers of one
+        const unsigned per_gpu = 4u * (unsigned)std::max<size_t>(1, gpus_.size());
+        const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), std::max(1u, std::min(per_gpu, hw / 4)));
+        const unsigned n_write = std::max(1u, std::min(per_gpu, hw / 4));
         std::vector<std::thread> loaders, renderers, writers;
         for (unsigned i = 0; i < n_load; ++i) loaders.emplace_back([this] { load_loop(); });
         for (unsigned i = 0; i < n_write; ++i) writers.emplace_back([this] { write_loop(); });
