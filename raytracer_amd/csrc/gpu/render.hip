@@ -204,7 +204,16 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
         W.accum[(size_t)W.capacity + g] = 0.f;
         W.accum[2 * (size_t)W.capacity + g] = 0.f;
     }
-    const int shard = blockIdx.x % N_SHARDS;
+    // A workgroup holds one sample of a quarter tile.  Its shard follows the quarter tile and turns with the sample
+    // (37 is odd: 64 samples visit 64 shards), so the samples of an expensive part of the image are spread over all shards
+    // whatever the batch size: a shard is walked by its own workgroups only, and the slowest shard ends a launch.  (With
+    // blockIdx % 64 a batch of 408 tiles sent every quarter tile to two shards, one of 736 tiles to one.)  Per sample a
+    // shard still gets its even share of workgroups, give or take one.
+#ifndef RT_SHARD_TURN
+#define RT_SHARD_TURN 37
+#endif
+    const unsigned per_sample = (unsigned)b.n_pixels >> 8;   // workgroups per sample (n_pixels is a multiple of 1024)
+    const int shard = (int)((blockIdx.x % per_sample + (blockIdx.x / per_sample) * RT_SHARD_TURN) % N_SHARDS);
     const unsigned local = wave_append(valid, counter_of(W, Q_PATH, 0, shard));
     const unsigned idx = shard * W.shard_entries + local;
     if (valid && local >= W.shard_entries) {
@@ -357,10 +366,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         pf_busy += __popcll(__ballot(r.cur != REF_IDLE));
         if (const unsigned long long m = __ballot(r.cur == REF_POP)) ++pf_pop_it, pf_pop_ln += __popcll(m);
 #endif
-        // (the stack loop runs for a few lanes at a time; with pop_min > 1 it waits until that many want it, or until no
-        // lane has a node or a leaf to go on with)
+        // (closest hit: the stack loop runs for a few lanes at a time -- entries that no longer qualify are dropped one per
+        // step, spilled ones are only taken here; with pop_min > 1 it waits until that many lanes want it, or until no lane
+        // has a node or a leaf to go on with.  An any-hit ray takes every entry inside its step, and only pays for the vote:
+        // +6 % on a frame of short shadow rays)
         bool run_pop = true;
-        if (!COUNT && tune.pop_min > 1) {
+        if (!COUNT && !ANY && tune.pop_min > 1) {
             const int n_pop = __popcll(__ballot(r.cur == REF_POP));
             run_pop = n_pop >= tune.pop_min || __ballot(r.cur != REF_POP && r.cur != REF_IDLE) == 0;
         }
@@ -2047,6 +2058,23 @@ static void read_stats(rt_scene *s, rt_stats *st, float kernel_ms, float total_m
 // Renders the tiles of `rank` of `world` into device memory: at their places in the full frame `dev_out` (resx * resy * 3
 // floats; other pixels untouched), or with `packed` tile after tile in the order of the rank's list (3072 floats per tile).
 // Returns with the stream drained; kernel_ms = device time between the first and the last kernel.
+// The most workgroups generate_kernel deals to one shard for a batch of `per_sample` workgroups per sample and `samples`
+// samples: every sample gives each shard per_sample / 64 of them and one more to the per_sample % 64 shards that follow
+// the sample's turn (see generate_kernel).
+static unsigned long long max_shard_groups(unsigned per_sample, unsigned samples) {
+    const unsigned full = per_sample / N_SHARDS, extra = per_sample % N_SHARDS;
+    if (!extra || !samples) return (unsigned long long)full * samples;
+    if (RT_SHARD_TURN % 2 == 0) return (unsigned long long)(full + 1) * samples;   // (test builds without the turn)
+    // whole turns of 64 samples visit every start once: each shard gets `extra` of those
+    const unsigned long long rounds = samples / N_SHARDS;
+    unsigned count[N_SHARDS] = {0};
+    for (unsigned k = 0; k < samples % N_SHARDS; ++k)
+        for (unsigned e = 0; e < extra; ++e) ++count[(k * RT_SHARD_TURN + e) % N_SHARDS];
+    unsigned most = 0;
+    for (unsigned v : count) most = std::max(most, v);
+    return (unsigned long long)full * samples + rounds * extra + most;
+}
+
 static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int world, float *dev_out, bool packed, float &kernel_ms) {
     int grid_n, n_samples;
     if (int rc = check_camera(s, cam, grid_n, n_samples)) return rc;
@@ -2104,11 +2132,16 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         unsigned long long slots_max = std::min<unsigned long long>(W.capacity, (unsigned long long)W.shadow_shard_entries * N_SHARDS / slots_per_vertex) / growth;
         if (growth > 1 || pt) slots_max = slots_max * 3 / 4;
         long long per_tile = 1024ll * n_samples;
-        // the tiles that are left go into as few batches as hold them, in equal parts (a last batch that is a fraction of
-        // the others costs more per tile: 8 shards of the 4K frame took 251-261 ms as 737 + 275 tiles, 252-254 ms in halves)
-        const long long most = std::max<long long>(1, (long long)slots_max / per_tile), left = n_owned - tile;
-        const long long batches_left = (left + most - 1) / most;
-        int tiles_now = (int)((left + batches_left - 1) / batches_left);
+        // (a multiple of 16 tiles = of 64 workgroups per sample: every shard then gets exactly its share; with any other
+        // count a shard gets at most one workgroup more per sample, which a batch below the multiple still has room for)
+        long long most = std::max<long long>(1, (long long)slots_max / per_tile);
+        if (most >= 32) most &= ~15ll;
+        int tiles_now = (int)std::min<long long>(n_owned - tile, most);
+        // the camera paths of the batch must fit the fullest shard
+        while (tiles_now > 1 && max_shard_groups(4u * (unsigned)tiles_now, (unsigned)n_samples) * 256ull > W.shard_entries)
+            tiles_now = tiles_now > 16 ? ((tiles_now - 1) & ~15) : tiles_now - 1;
+        if (getenv("RT_PRINT_BATCHES"))   // diagnostic
+            fprintf(stderr, "batch: %d tiles of %d left (a batch holds %lld; %u slots per vertex, growth %u)\n", tiles_now, n_owned - tile, most, slots_per_vertex, growth);
         Batch b;
         b.tile_first = tile;
         b.tile_count = tiles_now;
