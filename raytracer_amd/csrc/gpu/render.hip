@@ -2209,6 +2209,18 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
         harvest_timers(s);
+        if (getenv("RT_PRINT_BATCHES")) {   // diagnostic: how evenly the shards were filled, generation by generation
+            std::vector<unsigned> words(counter_words(W.generations));
+            if (hipMemcpy(words.data(), W.counters, words.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
+                for (int g = 0; g < n_gen; ++g) {
+                    unsigned long long sum = 0, most = 0;
+                    for (int sh = 0; sh < N_SHARDS; ++sh) {
+                        const unsigned v = words[((size_t)(Q_PATH * W.generations + g) * N_SHARDS + sh) * COUNTER_STRIDE];
+                        sum += v, most = std::max<unsigned long long>(most, v);
+                    }
+                    if (sum) fprintf(stderr, "  generation %d: %llu paths, fullest shard / mean %.4f\n", g, sum, (double)most * N_SHARDS / (double)sum);
+                }
+        }
         if (*s->host_flags) {   // a queue ran out of room: this batch again, with fewer camera samples in flight
             if (tiles_now == 1 && growth > 4096) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
