@@ -310,9 +310,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
     // diagnostic build: per wave, iterations and participating lanes of each kind of step (closest-hit kernel only),
     // reported through the work-counter words that are otherwise zero without counters
     unsigned pf_node_it = 0, pf_node_ln = 0, pf_leaf_it = 0, pf_leaf_ln = 0, pf_pop_it = 0, pf_pop_ln = 0, pf_it = 0, pf_busy = 0;
+    // 3 (closest hit) / 4 (any hit): a wave's lifetime and the part of it after its shard's queue ran dry, in 100 MHz ticks
+    const unsigned long long pf_t0 = wall_clock64();
+    unsigned long long pf_dry = 0;
 #endif
 
     for (;;) {
+#ifdef RT_TRACE_PROFILE
+        if (exhausted && !pf_dry) pf_dry = wall_clock64();
+#endif
         const unsigned long long idle = __ballot(r.cur == REF_IDLE);
         if (idle) {
             if (!exhausted) {
@@ -461,7 +467,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         }
     }
 #ifdef RT_TRACE_PROFILE
-    if (ANY == (RT_TRACE_PROFILE == 2) && lane == 0) {   // 1: the closest-hit kernel's waves, 2: the any-hit kernel's
+    if (RT_TRACE_PROFILE >= 3 && ANY == (RT_TRACE_PROFILE == 4) && lane == 0) {
+        const unsigned long long t1 = wall_clock64();
+        unsigned long long *row = stats + (blockIdx.x % STAT_ROWS) * STAT_WORDS;
+        atomicAdd(row + 3, t1 - pf_t0);                       // lifetime
+        atomicAdd(row + 4, pf_dry ? t1 - pf_dry : 0ull);      // after the queue ran dry
+        atomicAdd(row + 5, 1ull);                             // waves
+        atomicAdd(row + 6, (unsigned long long)pf_it);        // iterations
+    }
+    if (RT_TRACE_PROFILE < 3 && ANY == (RT_TRACE_PROFILE == 2) && lane == 0) {   // 1: the closest-hit kernel's waves, 2: the any-hit kernel's
         unsigned long long *row = stats + (blockIdx.x % STAT_ROWS) * STAT_WORDS;
         const unsigned vals[8] = {pf_node_it, pf_node_ln, pf_leaf_it, pf_leaf_ln, pf_pop_it, pf_pop_ln, pf_it, pf_busy};
         for (int k = 0; k < 4; ++k) atomicAdd(row + 3 + k, (unsigned long long)vals[k]);
