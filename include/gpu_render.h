@@ -281,6 +281,14 @@ int rt_render_shard(rt_scene *scene, const rt_camera_desc *cam, int32_t rank, in
  * what lets every rank know the layout without communication.) */
 int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner_out);
 
+/* Host-only test hook (no reference counterpart: the reference has no queues).  Inside a device a batch of camera
+ * samples is dealt to 64 queue shards, one workgroup = one sample of a quarter tile at a time: workgroup `q` of sample `s`
+ * goes to shard (q + 37 s) mod 64.  rt_queue_shard_of returns that shard; rt_queue_fill_bound the most workgroups one
+ * shard receives for `groups_per_sample` workgroups per sample and `samples` samples, which is what the batch planner
+ * checks against the room of a shard.  Touch no GPU. */
+int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample);
+uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples);
+
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders
  * the rank's tiles into a packed tile-major buffer, moves the buffers to rank 0 in one grouped RCCL send / receive and,

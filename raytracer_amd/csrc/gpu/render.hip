@@ -188,6 +188,12 @@ __device__ __forceinline__ void flush_counters(const Counters &c, unsigned long 
     }
 }
 
+#ifndef RT_SHARD_TURN
+#define RT_SHARD_TURN 37
+#endif
+// The queue shard of workgroup `group` (one sample of a quarter tile) of sample `sample`: see generate_kernel.
+__host__ __device__ __forceinline__ int queue_shard_of(unsigned group, unsigned sample) { return (int)((group + sample * RT_SHARD_TURN) % N_SHARDS); }
+
 // ---- generate: camera::get_samples (src/camera.cpp:117-224) for every (pixel, sample) of the batch ----------
 __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch b, Wavefront W, unsigned long long *__restrict__ stats) {
     const unsigned g = blockIdx.x * 256u + threadIdx.x;
@@ -209,11 +215,8 @@ __global__ void __launch_bounds__(256) generate_kernel(rt_camera_desc cam, Batch
     // whatever the batch size: a shard is walked by its own workgroups only, and the slowest shard ends a launch.  (With
     // blockIdx % 64 a batch of 408 tiles sent every quarter tile to two shards, one of 736 tiles to one.)  Per sample a
     // shard still gets its even share of workgroups, give or take one.
-#ifndef RT_SHARD_TURN
-#define RT_SHARD_TURN 37
-#endif
     const unsigned per_sample = (unsigned)b.n_pixels >> 8;   // workgroups per sample (n_pixels is a multiple of 1024)
-    const int shard = (int)((blockIdx.x % per_sample + (blockIdx.x / per_sample) * RT_SHARD_TURN) % N_SHARDS);
+    const int shard = queue_shard_of(blockIdx.x % per_sample, blockIdx.x / per_sample);
     const unsigned local = wave_append(valid, counter_of(W, Q_PATH, 0, shard));
     const unsigned idx = shard * W.shard_entries + local;
     if (valid && local >= W.shard_entries) {
@@ -2309,6 +2312,9 @@ int rt_render_shard(rt_scene *s, const rt_camera_desc *cam, int32_t rank, int32_
 }
 
 int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats) { return rt_render_shard(s, cam, 0, 1, hdr_out, stats); }
+
+int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample) { return queue_shard_of(group_of_sample, sample); }
+uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { return max_shard_groups(groups_per_sample, samples); }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major
 // order, which is the order of its packed buffer.

@@ -107,3 +107,29 @@ def test_two_rank_gather_is_byte_identical(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path / "full.npy"), str(tmp_path / "out.npy")), nprocs=2, join=True)
     out = np.load(tmp_path / "out.npy")
     assert out.tobytes() == full.tobytes()
+
+
+def test_queue_shards_get_an_even_share_and_the_planner_knows_the_fullest():
+    """Inside a device the camera samples of a batch are dealt to 64 queue shards (workgroup q of sample s -> shard
+    (q + 37 s) mod 64): every quarter tile visits every shard within 64 samples, a shard's share of a batch stays within one
+    workgroup per sample of the mean, and rt_queue_fill_bound is exactly the fullest shard's count."""
+    import ctypes as C
+    import raytracer_amd as R
+    g = R.gpu_lib()
+    g.rt_queue_shard_of.restype = C.c_int32
+    g.rt_queue_shard_of.argtypes = [C.c_uint32, C.c_uint32]
+    g.rt_queue_fill_bound.restype = C.c_uint64
+    g.rt_queue_fill_bound.argtypes = [C.c_uint32, C.c_uint32]
+    assert sorted(g.rt_queue_shard_of(5, s) for s in range(64)) == list(range(64))
+    rng = np.random.default_rng(7)
+    cases = [(4, 16), (4, 64), (1632, 64), (2944, 256), (2948, 256), (100, 1), (63, 7), (65, 100), (2500, 16)]
+    cases += [(int(a), int(b)) for a, b in zip(rng.integers(1, 400, 12), rng.integers(1, 300, 12))]
+    for groups, samples in cases:
+        q = np.arange(groups, dtype=np.int64)[None, :]
+        s = np.arange(samples, dtype=np.int64)[:, None]
+        fill = np.bincount(((q + 37 * s) % 64).ravel(), minlength=64)
+        assert g.rt_queue_shard_of(groups - 1, samples - 1) == (groups - 1 + 37 * (samples - 1)) % 64
+        assert g.rt_queue_fill_bound(groups, samples) == fill.max(), (groups, samples)
+        assert fill.max() - fill.min() <= min(samples, 64), (groups, samples)
+        if groups % 64 == 0 or samples % 64 == 0:
+            assert fill.max() == fill.min()
