@@ -1319,7 +1319,21 @@ struct rt_scene {
     std::vector<Bracket> brackets;
     double kernel_ms[RT_KERNEL_COUNT] = {};
     unsigned long long kernel_launches[RT_KERNEL_COUNT] = {};
+    // A frame that fits one batch is some forty short launches (1080p / 1 spp: 1.1 ms of kernels): when the same frame is
+    // asked for again -- same camera, same buffers -- its launch sequence is captured once into a HIP graph and replayed.
+    unsigned long long frame_key_seen = 0;    // key of the last single-batch frame that was launched kernel by kernel
+    unsigned long long frame_graph_key = 0;   // key the graph below was captured for (0: none)
+    hipGraph_t frame_graph = nullptr;
+    hipGraphExec_t frame_graph_exec = nullptr;
 };
+
+static void drop_frame_graph(rt_scene *s) {
+    if (s->frame_graph_exec) (void)hipGraphExecDestroy(s->frame_graph_exec);
+    if (s->frame_graph) (void)hipGraphDestroy(s->frame_graph);
+    s->frame_graph_exec = nullptr;
+    s->frame_graph = nullptr;
+    s->frame_graph_key = 0;
+}
 
 // Times one kernel launch when profiling is on: records an event before and (on destruction) after it.
 struct LaunchTimer {
@@ -1932,6 +1946,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     (void)hipSetDevice(s->device);
+    drop_frame_graph(s);
     park_wavefront(s);
     for (void *p : s->allocations) (void)hipFree(p);
     for (void *p : s->wf_allocations) (void)hipFree(p);
@@ -2169,61 +2184,101 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         b.owned = owned;
         b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
-        HIP_OK(hipMemsetAsync(W.counters, 0, counter_words(W.generations) * sizeof(unsigned), s->stream));
-        // the frame's counters as they stand before this batch, should the batch have to be done again
-        HIP_OK(hipMemcpyAsync(s->stats + STAT_ROWS * STAT_WORDS, s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
-        {
-            LaunchTimer timer(s, RT_KERNEL_GENERATE, s->stream);
-            hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
-        }
-        // consumer grids: a whole number of workgroups per shard
-        const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
-        const unsigned grid = per_shard * N_SHARDS;
-        // `stream` walks the paths (closest hit, shade); `lighting` (the same stream unless RT_TWO_STREAMS is set) lights
-        // the vertices of a generation, with two streams while `stream` already traces the next one.  Vertex and shadow
-        // buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
-        for (int gen = 0; gen < n_gen; ++gen) {
-            launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
-            if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));
+        // everything the batch puts on the stream(s), in order
+        auto issue_batch = [&]() -> int {
+            HIP_OK(hipMemsetAsync(W.counters, 0, counter_words(W.generations) * sizeof(unsigned), s->stream));
+            // the frame's counters as they stand before this batch, should the batch have to be done again
+            HIP_OK(hipMemcpyAsync(s->stats + STAT_ROWS * STAT_WORDS, s->stats, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
             {
-                LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
-                if (pt)
-                    hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
-                else
-                    hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
+                LaunchTimer timer(s, RT_KERNEL_GENERATE, s->stream);
+                hipLaunchKernelGGL(generate_kernel, dim3((slots + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, s->stats);
             }
-            HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
-            HIP_OK(hipStreamWaitEvent(lighting, s->shaded[gen], 0));
-            const int n_pass = (s->k_total + 63) / 64;
-            if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
-                launch_trace(s, lighting, true, grid, gen, 1);
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, 2, s->stats);
-            }
-            for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {                if (pass > 0)
-                    HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
-                                          N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
+            // consumer grids: a whole number of workgroups per shard
+            const unsigned per_shard = (unsigned)std::min<unsigned long long>(grid_cap / N_SHARDS, std::max<unsigned long long>(1, ((unsigned long long)slots * growth / N_SHARDS + 255) / 256));
+            const unsigned grid = per_shard * N_SHARDS;
+            // `stream` walks the paths (closest hit, shade); `lighting` (the same stream unless RT_TWO_STREAMS is set) lights
+            // the vertices of a generation, with two streams while `stream` already traces the next one.  Vertex and shadow
+            // buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
+            for (int gen = 0; gen < n_gen; ++gen) {
+                launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
+                if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));
                 {
-                    LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
-                    hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
+                    LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
+                    if (pt)
+                        hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
+                    else
+                        hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
                 }
-                launch_trace(s, lighting, true, grid, gen, 0);
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
+                HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
+                HIP_OK(hipStreamWaitEvent(lighting, s->shaded[gen], 0));
+                const int n_pass = (s->k_total + 63) / 64;
+                if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
+                    launch_trace(s, lighting, true, grid, gen, 1);
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, 2, s->stats);
+                }
+                for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {                if (pass > 0)
+                        HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
+                                              N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
+                    {
+                        LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
+                        hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
+                    }
+                    launch_trace(s, lighting, true, grid, gen, 0);
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
+                }
+                if (n_pass == 0 && !pt) {   // ambient only
+                    LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, -1, 0, 0, s->stats);
+                }
+                HIP_OK(hipEventRecord(s->lit[gen], lighting));
             }
-            if (n_pass == 0 && !pt) {   // ambient only
-                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, -1, 0, 0, s->stats);
+            for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
+            {
+                LaunchTimer timer(s, RT_KERNEL_RESOLVE, s->stream);
+                hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out, packed ? 1 : 0);
             }
-            HIP_OK(hipEventRecord(s->lit[gen], lighting));
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+            return 0;
+        };
+        // A frame of one batch that is asked for a second time with the same camera, buffers and state is captured into a
+        // HIP graph and replayed from then on: its forty-odd short launches become one (RT_FRAME_GRAPH=0: never).
+        static const bool graphs_allowed = !(getenv("RT_FRAME_GRAPH") && atoi(getenv("RT_FRAME_GRAPH")) == 0);
+        unsigned long long key = 0;
+        if (graphs_allowed && !s->profiling && !s->counters && !two_streams && tile == 0 && tiles_now == n_owned && !getenv("RT_PRINT_BATCHES")) {
+            key = 1469598103934665603ull;
+            auto mix = [&](const void *p, size_t n) {
+                for (size_t i = 0; i < n; ++i) key = (key ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+            };
+            const unsigned long long words[] = {(unsigned long long)rank, (unsigned long long)world, (unsigned long long)packed, (unsigned long long)(uintptr_t)dev_out,
+                                                (unsigned long long)(uintptr_t)W.counters, W.capacity, W.shadow_shard_entries, (unsigned long long)emitter_rays,
+                                                (unsigned long long)share_rays, growth, (unsigned long long)n_gen, slots_per_vertex, (unsigned long long)tiles_now,
+                                                (unsigned long long)(uintptr_t)owned, (unsigned long long)(uintptr_t)s->dev.wnodes, (unsigned long long)W.generations};
+            mix(cam, sizeof *cam);
+            mix(words, sizeof words);
+            key |= 1ull;   // (0 means "none")
         }
-        for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
-        {
-            LaunchTimer timer(s, RT_KERNEL_RESOLVE, s->stream);
-            hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out, packed ? 1 : 0);
+        if (key && s->frame_graph_exec && s->frame_graph_key == key) {
+            HIP_OK(hipGraphLaunch(s->frame_graph_exec, s->stream));
+        } else if (key && s->frame_key_seen == key) {   // the second time: capture, then run what was captured
+            drop_frame_graph(s);
+            HIP_OK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = issue_batch();
+            const hipError_t ended = hipStreamEndCapture(s->stream, &s->frame_graph);
+            if (rc) {
+                drop_frame_graph(s);
+                return rc;
+            }
+            HIP_OK(ended);
+            HIP_OK(hipGraphInstantiate(&s->frame_graph_exec, s->frame_graph, nullptr, nullptr, 0));
+            s->frame_graph_key = key;
+            HIP_OK(hipGraphLaunch(s->frame_graph_exec, s->stream));
+        } else {
+            s->frame_key_seen = key;
+            if (int rc = issue_batch()) return rc;
         }
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipMemcpyAsync(s->host_flags, W.overflow, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
         HIP_OK(hipStreamSynchronize(s->stream));
         harvest_timers(s);
         if (getenv("RT_PRINT_BATCHES")) {   // diagnostic: how evenly the shards were filled, generation by generation
@@ -2239,6 +2294,8 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 }
         }
         if (*s->host_flags) {   // a queue ran out of room: this batch again, with fewer camera samples in flight
+            drop_frame_graph(s);
+            s->frame_key_seen = 0;
             if (tiles_now == 1 && growth > 4096) {
                 g_error = "path queue overflow: the scene branches more than the wavefront capacity allows (set RT_WAVEFRONT_CAPACITY)";
                 return 6;

@@ -233,3 +233,33 @@ def test_command_line_directory_of_frames(tmp_path, render_threads):
         sc = R.Scene(str(frames / f"anim_{k:04d}.json"))
         img, _ = R.Renderer(sc).render(sc.camera(0))
         assert np.array_equal(png_pixels(str(tmp_path / "outputs" / f"anim_{k:04d}.png")), R.gpu_quantize_ldr(img)[::-1])
+
+
+def test_repeated_frame_is_replayed_from_a_graph_with_the_same_result(tmp_path):
+    """A frame of one batch that is asked for again with the same camera and buffers is captured into a HIP graph (second
+    request) and replayed (third and later): every repetition gives the first frame's image and statistics, a different
+    camera in between goes the ordinary way, and RT_FRAME_GRAPH=0 gives the same image."""
+    import subprocess, sys
+    sc = R.Scene(os.path.join(ROOT, "scenes", "simple.json"))
+    ren = R.Renderer(sc)
+    cam = sc.camera(0)
+    first, st0 = ren.render(cam)
+    for _ in range(4):
+        img, st = ren.render(cam)
+        assert np.array_equal(img, first)
+        assert (st.primary_rays, st.shadow_rays, st.secondary_rays, st.shaded_hits) == (st0.primary_rays, st0.shadow_rays, st0.secondary_rays, st0.shaded_hits)
+    other = sc.camera(0)
+    other.position[0] += 0.25
+    moved, _ = ren.render(other)
+    assert not np.array_equal(moved, first)
+    again, _ = ren.render(cam)
+    assert np.array_equal(again, first)
+    moved2, _ = ren.render(other)
+    moved3, _ = ren.render(other)
+    assert np.array_equal(moved2, moved) and np.array_equal(moved3, moved)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import raytracer_amd as R; sc = R.Scene(%r); ren = R.Renderer(sc); cam = sc.camera(0);"
+            "imgs = [ren.render(cam)[0] for _ in range(3)]; np.save(%r, imgs[2]); assert all(np.array_equal(i, imgs[0]) for i in imgs)"
+            % (ROOT, os.path.join(ROOT, "scenes", "simple.json"), str(tmp_path / "plain.npy")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_FRAME_GRAPH="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.load(tmp_path / "plain.npy"), first)
