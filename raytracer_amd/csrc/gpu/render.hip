@@ -1322,6 +1322,7 @@ struct rt_scene {
     unsigned long long kernel_launches[RT_KERNEL_COUNT] = {};
     // A frame that fits one batch is some forty short launches (1080p / 1 spp: 1.1 ms of kernels): when the same frame is
     // asked for again -- same camera, same buffers -- its launch sequence is captured once into a HIP graph and replayed.
+    bool frame_graph_off = false;             // a capture failed: no further attempts for this scene
     unsigned long long frame_key_seen = 0;    // key of the last single-batch frame that was launched kernel by kernel
     unsigned long long frame_graph_key = 0;   // key the graph below was captured for (0: none)
     hipGraph_t frame_graph = nullptr;
@@ -2254,7 +2255,8 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         // HIP graph and replayed from then on: its forty-odd short launches become one (RT_FRAME_GRAPH=0: never).
         static const bool graphs_allowed = !(getenv("RT_FRAME_GRAPH") && atoi(getenv("RT_FRAME_GRAPH")) == 0);
         unsigned long long key = 0;
-        if (graphs_allowed && !s->profiling && !s->counters && !two_streams && tile == 0 && tiles_now == n_owned && !getenv("RT_PRINT_BATCHES")) {
+        if (graphs_allowed && !s->frame_graph_off && world == 1 && !s->profiling && !s->counters && !two_streams && tile == 0 && tiles_now == n_owned &&
+            !getenv("RT_PRINT_BATCHES")) {
             key = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t n) {
                 for (size_t i = 0; i < n; ++i) key = (key ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
@@ -2271,17 +2273,25 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             HIP_OK(hipGraphLaunch(s->frame_graph_exec, s->stream));
         } else if (key && s->frame_key_seen == key) {   // the second time: capture, then run what was captured
             drop_frame_graph(s);
-            HIP_OK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = issue_batch();
-            const hipError_t ended = hipStreamEndCapture(s->stream, &s->frame_graph);
-            if (rc) {
-                drop_frame_graph(s);
-                return rc;
+            bool captured = hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (captured) {
+                const int rc = issue_batch();
+                captured = hipStreamEndCapture(s->stream, &s->frame_graph) == hipSuccess && rc == 0 && s->frame_graph &&
+                           hipGraphInstantiate(&s->frame_graph_exec, s->frame_graph, nullptr, nullptr, 0) == hipSuccess;
             }
-            HIP_OK(ended);
-            HIP_OK(hipGraphInstantiate(&s->frame_graph_exec, s->frame_graph, nullptr, nullptr, 0));
-            s->frame_graph_key = key;
-            HIP_OK(hipGraphLaunch(s->frame_graph_exec, s->stream));
+            if (captured) {
+                s->frame_graph_key = key;
+                HIP_OK(hipGraphLaunch(s->frame_graph_exec, s->stream));
+            } else {
+                // A capture can be broken from outside (another thread's synchronous copy on the device's default stream is an
+                // implicit dependency on the capturing stream).  Nothing has run: the batch goes the ordinary way, and this
+                // scene stops trying.
+                drop_frame_graph(s);
+                (void)hipGetLastError();
+                s->frame_graph_off = true;
+                s->frame_key_seen = 0;
+                if (int rc = issue_batch()) return rc;
+            }
         } else {
             s->frame_key_seen = key;
             if (int rc = issue_batch()) return rc;
