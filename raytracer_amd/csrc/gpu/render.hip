@@ -168,6 +168,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // Float atomics run at the memory side in 64-byte requests: with one plane per colour, lanes whose slots are neighbours
 // share a request.
 __device__ __forceinline__ void accum_add(const Wavefront &W, int slot, V v) {
+    // (a contribution of zero -- a path that leaves a scene with a black background, a vertex in shadow without an ambient
+    // term -- changes no sum: the sums start at +0 and x + 0 = x; skipping it saves three atomics)
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return;
     unsafeAtomicAdd(W.accum + (size_t)slot, v.x);
     unsafeAtomicAdd(W.accum + (size_t)W.capacity + (size_t)slot, v.y);
     unsafeAtomicAdd(W.accum + 2 * (size_t)W.capacity + (size_t)slot, v.z);
