@@ -104,8 +104,7 @@ struct ShadowQueue {
 
 struct Wavefront {
     PathQueue q[2];
-    float *hit_t;
-    int *hit_prim;
+    float2 *hit;              // per path entry: closest distance, bits(leaf entry of the hit; <= -2 plane, -1 none, -3 depth limit): one 8-byte store per finished ray
     VertexBuf vtx[2];         // by generation parity: the direct lighting of generation g runs beside the
     ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
     unsigned shadow_shard_entries;   // shadow rays, and light-sample records, per shard
@@ -270,8 +269,7 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
         const bool in_shadow = prim != -1 && t < dist - eps;   // src/ray_trace.cpp:232-241
         W.shadow[gen & 1].vis[idx] = in_shadow ? 0.f : 1.f;
     } else {
-        W.hit_t[idx] = t;
-        W.hit_prim[idx] = prim;
+        W.hit[idx] = make_float2(t, __int_as_float(prim));
     }
 }
 
@@ -570,8 +568,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
             culling = ((df >> 16) & 1) != 0;
             const bool diffuse_bounce = ((df >> 17) & 1) != 0;
             Hit h;
-            h.prim = W.hit_prim[idx];
-            h.t = h.prim == -3 ? 0.f : W.hit_t[idx];
+            const float2 found = W.hit[idx];
+            h.prim = __float_as_int(found.y);
+            h.t = h.prim == -3 ? 0.f : found.x;
             float pixelu = 0.f, pixelv = 0.f;
             if (!PT && (h.prim == -1 || h.prim == -3) && !is_hdr && S.bg_tex >= 0) {
                 // LDR background images are looked up by pixel position (src/main.cpp:455-456); slots are laid out
@@ -1229,7 +1228,8 @@ __global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_
         int i, j;
         batch_pixel(b, (int)(slot % (unsigned)b.n_pixels), i, j);
         const size_t px = (size_t)j * cam.resx + i;
-        const int prim = W.hit_prim[idx];
+        const float2 found = W.hit[idx];
+        const int prim = __float_as_int(found.y);
         int shape = -1, id = -1;
         if (prim <= -2) {
             shape = S.n_triangles + S.n_spheres + (-2 - prim);
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256) primary_out_kernel(DevScene S, rt_camera_
         }
         shape_out[px] = shape;
         id_out[px] = id;
-        t_out[px] = prim == -1 ? 1e30f : W.hit_t[idx];
+        t_out[px] = prim == -1 ? 1e30f : found.x;
     }
 }
 
@@ -1418,7 +1418,7 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, i
              alloc((void **)&W.shadow[k].d_time, scap * 16) && alloc((void **)&W.shadow[k].fd_ray, scap * 16) &&
              alloc((void **)&W.shadow[k].fs_, scap * 16) && alloc((void **)&W.shadow[k].vis, scap * 4);
     }
-    ok = ok && alloc((void **)&W.hit_t, (size_t)cap * 4) && alloc((void **)&W.hit_prim, (size_t)cap * 4) &&
+    ok = ok && alloc((void **)&W.hit, (size_t)cap * 8) &&
          alloc((void **)&W.accum, (size_t)cap * 12) && alloc((void **)&W.counters, counter_words(generations) * sizeof(unsigned));
     if (!ok) {
         for (void *p : s->wf_allocations) (void)hipFree(p);
