@@ -108,6 +108,8 @@ struct Wavefront {
     VertexBuf vtx[2];         // by generation parity: the direct lighting of generation g runs beside the
     ShadowQueue shadow[2];    // closest-hit trace and shading of generation g + 1
     unsigned shadow_shard_entries;   // shadow rays, and light-sample records, per shard
+    int has_records;                 // the light-sample records (fd_ray, fs_) are allocated: a frame whose only light is one
+                                     // sphere emitter evaluated after its ray needs none (64 of an entry's 484 bytes)
     float *accum;             // radiance sums per slot: three planes (r, g, b) of `capacity` floats
     unsigned *counters;       // [3 kinds][generations][N_SHARDS] entry counts, one 128-byte line each, then the overflow flag
     int generations;          // generations the counters have room for
@@ -1385,7 +1387,7 @@ static size_t counter_words(int generations) { return (size_t)3 * generations * 
 // sixteen -- and RT_WAVEFRONT_CAPACITY overrides it.  Large batches matter: every kernel of a batch ends with a tail in
 // which the last rays finish on a mostly idle chip, and the fewer batches a frame has, the fewer tails it pays for
 // (4K / 64 spp frame of the 1M-triangle scene: 948 ms at 12 Mi entries, 857 at 24 Mi, 803 at 48 Mi, 775 at 96 Mi, 740 at 264 Mi).
-static unsigned wavefront_capacity(unsigned shadow_mult) {
+static unsigned wavefront_capacity(unsigned shadow_mult, bool records = true) {
     const unsigned long long unit = N_SHARDS * 256;
     if (const char *e = getenv("RT_WAVEFRONT_CAPACITY")) {
         long v = atol(e);
@@ -1395,12 +1397,12 @@ static unsigned wavefront_capacity(unsigned shadow_mult) {
     size_t free_bytes = 0, total_bytes = 0;   // share a device that is already in use: at most 3/4 of what is free
     if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) budget = std::min<unsigned long long>(budget, (unsigned long long)free_bytes / 4 * 3);
     (void)hipGetLastError();
-    const unsigned long long per_entry = 348ull + 136ull * shadow_mult;
+    const unsigned long long per_entry = 348ull + (records ? 136ull : 72ull) * shadow_mult;
     return (unsigned)(std::max<unsigned long long>(std::min<unsigned long long>(budget / per_entry, 1ull << 28) / unit, 4) * unit);
 }
 
 // Allocates the wavefront state for `cap` entries; on failure everything allocated so far is released.
-static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, int generations, Wavefront &W) {
+static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, int generations, bool records, Wavefront &W) {
     auto alloc = [&](void **p, size_t bytes) -> bool {
         if (hipMalloc(p, bytes) != hipSuccess) return false;
         s->wf_allocations.push_back(*p);
@@ -1415,8 +1417,8 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, i
              alloc((void **)&W.vtx[k].view_mat, (size_t)cap * 16) && alloc((void **)&W.vtx[k].kd_slot, (size_t)cap * 16) &&
              alloc((void **)&W.vtx[k].ks_n, (size_t)cap * 16) && alloc((void **)&W.vtx[k].weight, (size_t)cap * 16) &&
              alloc((void **)&W.vtx[k].amb_first, (size_t)cap * 16) && alloc((void **)&W.shadow[k].o_dist, scap * 16) &&
-             alloc((void **)&W.shadow[k].d_time, scap * 16) && alloc((void **)&W.shadow[k].fd_ray, scap * 16) &&
-             alloc((void **)&W.shadow[k].fs_, scap * 16) && alloc((void **)&W.shadow[k].vis, scap * 4);
+             alloc((void **)&W.shadow[k].d_time, scap * 16) && alloc((void **)&W.shadow[k].vis, scap * 4) &&
+             (!records || (alloc((void **)&W.shadow[k].fd_ray, scap * 16) && alloc((void **)&W.shadow[k].fs_, scap * 16)));
     }
     ok = ok && alloc((void **)&W.hit, (size_t)cap * 8) &&
          alloc((void **)&W.accum, (size_t)cap * 12) && alloc((void **)&W.counters, counter_words(generations) * sizeof(unsigned));
@@ -1427,6 +1429,7 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, i
         return 10;
     }
     W.shadow_shard_entries = (unsigned)(scap / N_SHARDS);
+    W.has_records = records ? 1 : 0;
     W.generations = generations;
     W.overflow = W.counters + counter_words(generations) - 1;
     W.shard_entries = cap / N_SHARDS;
@@ -1475,13 +1478,13 @@ static bool park_wavefront(rt_scene *s) {
 // Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries and `shadow_floor` shadow slots
 // (what one batch of the smallest size needs); grows, never shrinks.  A new state gets `shadow_mult` shadow slots per
 // entry.  When the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
-static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned shadow_mult, unsigned long long shadow_floor, int generations) {
+static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned shadow_mult, unsigned long long shadow_floor, int generations, bool records = true) {
     // generate deals whole 256-lane workgroups to the shards, so a shard must hold ceil(workgroups / N_SHARDS) of them
     const unsigned long long unit = N_SHARDS * 256;
     wanted = std::max<unsigned long long>(65536, (wanted + unit - 1) / unit * unit);
-    unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity(shadow_mult));
+    unsigned cap = (unsigned)std::min<unsigned long long>(wanted, wavefront_capacity(shadow_mult, records));
     auto enough = [&](const Wavefront &W) {
-        return W.capacity >= cap && W.generations >= generations &&
+        return W.capacity >= cap && W.generations >= generations && (W.has_records || !records) &&
                (unsigned long long)W.shadow_shard_entries * N_SHARDS >= std::min<unsigned long long>(shadow_floor, (unsigned long long)cap * shadow_mult);
     };
     if (enough(s->wf)) return 0;
@@ -1497,7 +1500,7 @@ static int ensure_wavefront(rt_scene *s, unsigned long long wanted, unsigned sha
     s->wf = Wavefront{};
     for (;;) {
         Wavefront W{};
-        if (allocate_wavefront(s, cap, shadow_mult, std::max(generations, 8), W) == 0) {
+        if (allocate_wavefront(s, cap, shadow_mult, std::max(generations, 8), records, W) == 0) {
             s->wf = W;
             return 0;
         }
@@ -2140,7 +2143,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     static const bool fuse_allowed = !(getenv("RT_FUSED_EMITTER_RAYS") && atoi(getenv("RT_FUSED_EMITTER_RAYS")) == 0);
     const int emitter_rays = share_rays && s->single_sphere_emitter && fuse_allowed ? 1 : 0;
     if (int rc = ensure_wavefront(s, (unsigned long long)std::max(n_owned, 1) * 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex,
-                                  1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024, std::max(1, (int)ceilf(s->dev.max_depth) + 2)))
+                                  1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024, std::max(1, (int)ceilf(s->dev.max_depth) + 2), !emitter_rays))
         return rc;
     const Wavefront &W = s->wf;
     if ((unsigned long long)n_samples * 1024ull > W.capacity) {
@@ -2323,7 +2326,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             growth *= 2;
             // a small frame got a small wavefront state: let it hold at least one tile at the new bound
             if (int rc = ensure_wavefront(s, 1024ull * n_samples * growth * 4 / 3 + 1024, slots_per_vertex, 1024ull * n_samples * growth * slots_per_vertex * 4 / 3 + 1024,
-                                          std::max(1, (int)ceilf(s->dev.max_depth) + 2)))
+                                          std::max(1, (int)ceilf(s->dev.max_depth) + 2), !emitter_rays))
                 return rc;
             // only this batch is done again (its tiles are simply resolved a second time); the abandoned attempt's counts go
             HIP_OK(hipMemcpyAsync(s->stats, s->stats + STAT_ROWS * STAT_WORDS, STAT_ROWS * STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->stream));
