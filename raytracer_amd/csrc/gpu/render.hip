@@ -798,7 +798,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                     W.vtx[gen & 1].kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot | (v_scale != 1.0f ? (int)0x80000000 : 0)));
                     W.vtx[gen & 1].ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
                     W.vtx[gen & 1].weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
-                    W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
+                    // (path tracing has no ambient term, and with the emitter's ray written here no sample has a record: the
+                    // gather kernel is told not to read this record, defer = 3)
+                    if (!(PT && emitter_rays)) W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
                     if (emitter_rays) {
                         // The scene's only light is one sphere emitter, whose samples share one shadow ray per vertex (see
                         // light_setup_kernel): the ray is written here, ray i for vertex i, and no set-up pass runs.
@@ -1036,7 +1038,7 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
         if (defer != 0 && L.type == RT_LIGHT_SPHERE) {
             const rt_sphere &sph = S.spheres[L.sphere];
             bool lit = false;
-            if (active && defer == 2) {   // the shading kernel wrote the rays: ray i for vertex i
+            if (active && defer >= 2) {   // the shading kernel wrote the rays: ray i for vertex i
                 lit = Q.vis[shadow_base + vl] != 0.f;
             } else if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
                 const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
@@ -1135,7 +1137,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const bool on = lane < n_ready;
         const unsigned vl = mine[on ? lane : 0u];
         const unsigned v = shard_base + vl;
-        const float4 af = B.amb_first[v], w = B.weight[v];
+        const float4 af = defer == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : B.amb_first[v], w = B.weight[v];
         const unsigned long long have = (unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w);
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
         c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k_total, k0, kn, k_pad, slot_table, defer, on, on ? have : 0ull, c, cnt);
@@ -1146,7 +1148,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const unsigned vl = vbase + lane;
         const bool valid = vl < nv;
         const unsigned v = shard_base + (valid ? vl : vbase);
-        const float4 af = B.amb_first[v], w = B.weight[v];
+        const float4 af = defer == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : B.amb_first[v], w = B.weight[v];   // 3: as 2, and no ambient record was written
         unsigned long long have = has_records ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
         const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
         if (!room) {   // (light_setup_kernel has reported it; with the rays written by the shading kernel this is where it shows)
@@ -1160,7 +1162,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
                 const rt_light &L = S.lights[li];
                 kend = min(kn, light_of[k_total + li] + L.samples - k0);
                 if (L.type != RT_LIGHT_SPHERE) continue;
-                if (defer == 2) {
+                if (defer >= 2) {
                     if (valid && W.shadow[gen & 1].vis[shadow_base + vl] != 0.f) full = true;
                     continue;
                 }
@@ -2229,7 +2231,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
                     launch_trace(s, lighting, true, grid, gen, 1);
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, 2, s->stats);
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
                 }
                 for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {                if (pass > 0)
                         HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
