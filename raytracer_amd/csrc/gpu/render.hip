@@ -277,13 +277,23 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
 
 // WIDE: interior nodes are taken from the wide tree (four quantised boxes per 64-byte record, see wide_step) instead
 // of the two-box records.  The counting variants always walk the two-box records, whose visits are the reference's.
+// The any-hit walk of the wide tree gains from eight waves per SIMD where the closest-hit walk does best with six (4K /
+// 64 spp frame, closest / any hit: 6 waves 230.4 / 105.1 ms, 7 waves 232.3 / 103.4, 8 waves 236.1 / 101.9): it keeps eight
+// stack levels in LDS instead of eleven, which is what eight workgroups per CU leave room for.
+#ifndef RT_ANY_WAVES
+#define RT_ANY_WAVES 8
+#endif
+#ifndef RT_ANY_LDS_STACK
+#define RT_ANY_LDS_STACK 8
+#endif
 template <bool ANY, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ANY && WIDE ? RT_ANY_WAVES : RT_TRACE_WAVES, ANY && WIDE ? RT_ANY_WAVES : RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
     static_assert(!(WIDE && COUNT), "the counters follow the two-box walk");
-    __shared__ uint2 stack_lds[LDS_STACK * 256];
+    constexpr int LEVELS = ANY && WIDE ? RT_ANY_LDS_STACK : LDS_STACK;   // stack entries in LDS
+    __shared__ uint2 stack_lds[LEVELS * 256];
     __shared__ float4 top_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 1];
     uint2 *lds = stack_lds + threadIdx.x;
-    uint2 spill[SPILL_STACK];
+    uint2 spill[64 - LEVELS];
     const int n_top = TOP_NODES > 0 ? min(WIDE ? S.n_wtop : S.n_top, TOP_NODES) : 0;
     {
         const float4 *records = WIDE ? S.wnodes : S.nodes;
@@ -388,7 +398,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
             run_pop = n_pop >= tune.pop_min || __ballot(r.cur != REF_POP && r.cur != REF_IDLE) == 0;
         }
         if (run_pop && r.cur == REF_POP) {
-            if (!stack_pop<(!ANY || COUNT), COUNT>(r, lds, spill, c)) {
+            if (!stack_pop<(!ANY || COUNT), COUNT, LEVELS>(r, lds, spill, c)) {
                 ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                 r.cur = REF_IDLE;
             }
@@ -405,9 +415,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
         if (run_node) {
             if ((unsigned)r.cur < (unsigned)REF_POP) {
                 if (WIDE) {
-                    wide_step(S, r, lds, spill, top_nodes, n_top);
+                    wide_step<LEVELS>(S, r, lds, spill, top_nodes, n_top);
 #ifndef RT_NO_INLINE_POP
-                    if (r.cur == REF_POP && pop_inline<!ANY>(r, lds)) {
+                    if (r.cur == REF_POP && pop_inline<!ANY, LEVELS>(r, lds)) {
                         ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                         r.cur = REF_IDLE;
                     }
@@ -462,7 +472,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_TRA
                 }
 #ifndef RT_NO_INLINE_POP
                 if (WIDE && r.cur == REF_POP) {
-                    if (pop_inline<!ANY>(r, lds)) {
+                    if (pop_inline<!ANY, LEVELS>(r, lds)) {
                         ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                         r.cur = REF_IDLE;
                     }

@@ -191,11 +191,13 @@ constexpr int STACK_STRIDE = 256;   // lanes per workgroup = entries per LDS sta
 
 // The private part of the stack is accessed as volatile words so that its loads and stores stay separate
 // instructions from the LDS ones (merged, both would go through the slow generic address path).
+// LEVELS: the entries of this stack that live in LDS (the any-hit kernel trades three of them for two more waves per SIMD).
+template <int LEVELS = LDS_STACK>
 __device__ __forceinline__ void stack_push(RayState &r, uint2 *lds, uint2 *spill, uint2 e) {
-    if (r.sp < LDS_STACK) {
+    if (r.sp < LEVELS) {
         lds[r.sp * STACK_STRIDE] = e;
-    } else if (r.sp < LDS_STACK + SPILL_STACK) {
-        volatile unsigned *w = (volatile unsigned *)(spill + (r.sp - LDS_STACK));
+    } else if (r.sp < 64) {
+        volatile unsigned *w = (volatile unsigned *)(spill + (r.sp - LEVELS));
         w[0] = e.x;
         w[1] = e.y;
     } else {
@@ -257,6 +259,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 __device__ __forceinline__ f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, f2{b, b}, f2{c, c}); }
 
+template <int LEVELS = LDS_STACK>
 __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, const float4 *top, int n_top) {
     float4 n0, n1, n2, n3;
     if (TOP_NODES > 0 && r.cur < n_top) {
@@ -306,7 +309,7 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
     const bool h3 = (t3 <= m3) & (m3 > 0.0f) & (t3 < r.t);
     // the first position that passes is next; the others wait on the stack, the earliest on top
     const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
-    if (r.sp + 3 <= LDS_STACK) {   // all in LDS: store without branching, an entry above the top is never read
+    if (r.sp + 3 <= LEVELS) {   // all in LDS: store without branching, an entry above the top is never read
         int sp = r.sp;
         lds[sp * STACK_STRIDE] = make_uint2((unsigned)d3, __float_as_uint(t3));
         sp += p3 ? 1 : 0;
@@ -316,24 +319,24 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
         sp += p1 ? 1 : 0;
         r.sp = sp;
     } else {
-        if (p3) stack_push(r, lds, spill, make_uint2((unsigned)d3, __float_as_uint(t3)));
-        if (p2) stack_push(r, lds, spill, make_uint2((unsigned)d2, __float_as_uint(t2)));
-        if (p1) stack_push(r, lds, spill, make_uint2((unsigned)d1, __float_as_uint(t1)));
+        if (p3) stack_push<LEVELS>(r, lds, spill, make_uint2((unsigned)d3, __float_as_uint(t3)));
+        if (p2) stack_push<LEVELS>(r, lds, spill, make_uint2((unsigned)d2, __float_as_uint(t2)));
+        if (p1) stack_push<LEVELS>(r, lds, spill, make_uint2((unsigned)d1, __float_as_uint(t1)));
     }
     r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 
 // Pops until an entry whose box still starts before the closest hit; false when the stack is empty.  With
 // CHECK false (an any-hit ray never shortens, so every pushed entry still qualifies) the first entry is taken.
-template <bool CHECK, bool COUNT>
+template <bool CHECK, bool COUNT, int LEVELS = LDS_STACK>
 __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const uint2 *spill, Counters &c) {
     while (r.sp > 0) {
         --r.sp;
         uint2 e;
-        if (r.sp < LDS_STACK) {
+        if (r.sp < LEVELS) {
             e = lds[r.sp * STACK_STRIDE];
         } else {
-            const volatile unsigned *w = (const volatile unsigned *)(spill + (r.sp - LDS_STACK));
+            const volatile unsigned *w = (const volatile unsigned *)(spill + (r.sp - LEVELS));
             e.x = w[0];
             e.y = w[1];
         }
@@ -350,10 +353,10 @@ __device__ __forceinline__ bool stack_pop(RayState &r, const uint2 *lds, const u
 // lies in the LDS part of the stack; an entry that no longer qualifies is dropped and the lane stays at REF_POP, which
 // the next round of stack_pop continues from -- the same entries are taken in the same order.  Returns true when the
 // stack was empty: the ray is finished.
-template <bool CHECK>
+template <bool CHECK, int LEVELS = LDS_STACK>
 __device__ __forceinline__ bool pop_inline(RayState &r, const uint2 *lds) {
     if (r.sp == 0) return true;
-    if (r.sp <= LDS_STACK) {
+    if (r.sp <= LEVELS) {
         const uint2 e = lds[(r.sp - 1) * STACK_STRIDE];
         --r.sp;
         if (!CHECK || __uint_as_float(e.y) < r.t) r.cur = (int)e.x;
