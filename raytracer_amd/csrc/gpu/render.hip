@@ -2183,6 +2183,16 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     // are the kernels' own.
     static const bool two_streams = getenv("RT_TWO_STREAMS") != nullptr && atoi(getenv("RT_TWO_STREAMS")) != 0;
     hipStream_t lighting = two_streams ? s->stream2 : s->stream;
+    // What does pay is one pair: the gather of generation g - 1 (arithmetic: the emitter's samples) beside the shading of
+    // generation g (memory: queue records streamed).  Both wait for the closest-hit trace of g, which has the chip to itself
+    // like every trace launch; the gather goes to the second stream, everything else stays on the first.
+    // (4K / 64 spp frame of the 1M-triangle scene: 451.6 -> 440.1 ms; the two take 102 ms together instead of 118 in turn.)
+    // Path-traced frames only: a slot then receives the sums of both kernels in whichever order they arrive, and only
+    // there is the order of a slot's additions free already (recursive ray tracing keeps its frames bit for bit).
+    // RT_PAIR_GATHER=0: everything in turn on one stream.
+    const bool pair_allowed = !(getenv("RT_PAIR_GATHER") && atoi(getenv("RT_PAIR_GATHER")) == 0);   // (read per frame: a test turns it off and on)
+    const int n_pass_all = (s->k_total + 63) / 64;
+    const bool pair_gather = pair_allowed && pt && !two_streams && n_gen > 1 && (emitter_rays || n_pass_all == 1);
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -2225,8 +2235,22 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             // `stream` walks the paths (closest hit, shade); `lighting` (the same stream unless RT_TWO_STREAMS is set) lights
             // the vertices of a generation, with two streams while `stream` already traces the next one.  Vertex and shadow
             // buffers alternate by generation parity: shade(g) waits for the lighting of g - 2.
+            // the gather of generation `gen` (its only pass, when it is launched apart from the rest of the lighting)
+            auto launch_gather = [&](hipStream_t on, int gen) {
+                LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, on);
+                if (emitter_rays)
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
+                else
+                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[0] ? 1 : 0, s->stats);
+            };
             for (int gen = 0; gen < n_gen; ++gen) {
                 launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
+                if (pair_gather && gen >= 1) {   // the gather of the generation before, beside this generation's shading
+                    HIP_OK(hipEventRecord(s->shaded[gen], s->stream));   // (here: "closest hits of `gen` found", and with them the shadow rays of gen - 1)
+                    HIP_OK(hipStreamWaitEvent(s->stream2, s->shaded[gen], 0));
+                    launch_gather(s->stream2, gen - 1);
+                    HIP_OK(hipEventRecord(s->lit[gen - 1], s->stream2));
+                }
                 if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));
                 {
                     LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
@@ -2235,15 +2259,28 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                     else
                         hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
                 }
+                const int n_pass = n_pass_all;
+                if (pair_gather) {   // rays and any-hit trace in turn; the gather follows the next closest-hit trace (the last one: at once)
+                    if (!emitter_rays) {
+                        LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, s->stream);
+                        hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
+                    }
+                    launch_trace(s, s->stream, true, grid, gen, emitter_rays ? 1 : 0);
+                    if (gen == n_gen - 1) {
+                        launch_gather(s->stream, gen);
+                        HIP_OK(hipEventRecord(s->lit[gen], s->stream));
+                    }
+                    continue;
+                }
                 HIP_OK(hipEventRecord(s->shaded[gen], s->stream));
                 HIP_OK(hipStreamWaitEvent(lighting, s->shaded[gen], 0));
-                const int n_pass = (s->k_total + 63) / 64;
                 if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
                     launch_trace(s, lighting, true, grid, gen, 1);
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
                     hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
                 }
-                for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {                if (pass > 0)
+                for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {
+                    if (pass > 0)
                         HIP_OK(hipMemsetAsync(W.counters + (size_t)(Q_SHADOW * W.generations + gen) * N_SHARDS * COUNTER_STRIDE, 0,
                                               N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                     {
@@ -2273,7 +2310,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         // HIP graph and replayed from then on: its forty-odd short launches become one (RT_FRAME_GRAPH=0: never).
         static const bool graphs_allowed = !(getenv("RT_FRAME_GRAPH") && atoi(getenv("RT_FRAME_GRAPH")) == 0);
         unsigned long long key = 0;
-        if (graphs_allowed && !s->frame_graph_off && world == 1 && !s->profiling && !s->counters && !two_streams && tile == 0 && tiles_now == n_owned &&
+        if (graphs_allowed && !s->frame_graph_off && world == 1 && !s->profiling && !s->counters && !two_streams && !pair_gather && tile == 0 && tiles_now == n_owned &&
             !getenv("RT_PRINT_BATCHES")) {
             key = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t n) {

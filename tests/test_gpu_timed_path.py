@@ -73,3 +73,29 @@ def test_mesh_scene_known_answers_at_1080p(scene_dir, monkeypatch):
     assert (shape[px], ids[px]) == (51182, 1) and abs(float(t[px]) - 2.29568005) < 1e-5
     s0, i0, t0, _ = Oracle(sc).trace_primary(cam)
     assert np.array_equal(s0, shape) and np.array_equal(i0, ids) and np.array_equal(t0.view(np.uint32), t.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["pathtrace", "pt_uniform", "pt_env", "emitters", "one_sphere_emitter"])
+def test_gather_beside_shading_changes_nothing(name, scene_dir, repo_root, monkeypatch):
+    """Path-traced frames run the gather of a generation on a second stream beside the next generation's shading
+    (RT_PAIR_GATHER=0: everything in turn).  Same rays, same counts; the image agrees to the order of a sample's float
+    additions, and with the oracle to the bar of the timed path."""
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    if name == "one_sphere_emitter":   # the benchmark scene in small: the shading kernel writes the emitter's shadow rays itself
+        sc = R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt_small", n=48, width=96, height=54, spp=16))
+    else:
+        sc = R.Scene(scene_path(name, scene_dir, repo_root))
+    cam = sc.camera(0)
+    ren = R.Renderer(sc)
+    monkeypatch.setenv("RT_PAIR_GATHER", "0")
+    img0, st0 = ren.render(cam)
+    monkeypatch.setenv("RT_PAIR_GATHER", "1")
+    img1, st1 = ren.render(cam)
+    img2, st2 = ren.render(cam)
+    for st in (st1, st2):
+        assert (st.primary_rays, st.secondary_rays, st.shadow_rays, st.shadow_rays_traced) == (
+            st0.primary_rays, st0.secondary_rays, st0.shadow_rays, st0.shadow_rays_traced)
+    assert rel_err(img1, img0).max() < 1e-5 and rel_err(img2, img0).max() < 1e-5
+    ref, _ = Oracle(sc).render(cam)
+    err = rel_err(img1, ref).max(axis=2)
+    assert (err > 2e-4).mean() <= 2e-3
