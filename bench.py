@@ -355,6 +355,9 @@ def main():
         roof = {"bound": "hbm", "kernel": name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel_ms_per_launch": ms_per_launch, "launches_per_frame": launches_per_frame,
                 "kernel_ms_per_frame": {k: v[1] / args.steps for k, v in ktimes.items()},
+                "kernel_ms_note": "event times per kernel class; in path-traced frames the gather of a generation runs on a second stream "
+                                  "beside the next generation's shading, so the times of shade and light_gather overlap (their sum exceeds "
+                                  "their share of the frame; RT_PAIR_GATHER=0 runs them in turn)",
                 # the fixed accounting of the reference's two-child walk (32 B per node visit, 36 B per triangle test, ...):
                 # comparable across layouts, but LDS, L1 and L2 serve most of these bytes, so it is no bound of this kernel
                 "byte_model": {"bytes_per_launch": model_bytes_per_launch, "rate_GBps": model_rate,

@@ -2189,10 +2189,12 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     // (4K / 64 spp frame of the 1M-triangle scene: 451.6 -> 440.1 ms; the two take 102 ms together instead of 118 in turn.)
     // Path-traced frames only: a slot then receives the sums of both kernels in whichever order they arrive, and only
     // there is the order of a slot's additions free already (recursive ray tracing keeps its frames bit for bit).
-    // RT_PAIR_GATHER=0: everything in turn on one stream.
-    const bool pair_allowed = !(getenv("RT_PAIR_GATHER") && atoi(getenv("RT_PAIR_GATHER")) == 0);   // (read per frame: a test turns it off and on)
+    // Batches of at least 4 Mi slots only: a small frame's launches are short, the hand-over between the streams is not,
+    // and a repeated small frame is replayed from a graph instead (below).
+    // RT_PAIR_GATHER=0: everything in turn on one stream; =2: batches of any size.
+    const int pair_mode = getenv("RT_PAIR_GATHER") ? atoi(getenv("RT_PAIR_GATHER")) : 1;   // (read per frame: a test turns it off and on)
     const int n_pass_all = (s->k_total + 63) / 64;
-    const bool pair_gather = pair_allowed && pt && !two_streams && n_gen > 1 && (emitter_rays || n_pass_all == 1);
+    const bool pair_possible = pair_mode != 0 && pt && !two_streams && n_gen > 1 && (emitter_rays || n_pass_all == 1);
     const unsigned grid_cap = 4096;
     int tile = 0;
     while (tile < n_owned) {
@@ -2220,6 +2222,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         b.owned = owned;
         b.still = 0;
         const unsigned slots = (unsigned)b.n_pixels * (unsigned)n_samples;
+        const bool pair_gather = pair_possible && (pair_mode == 2 || slots >= (1u << 22));
         // everything the batch puts on the stream(s), in order
         auto issue_batch = [&]() -> int {
             HIP_OK(hipMemsetAsync(W.counters, 0, counter_words(W.generations) * sizeof(unsigned), s->stream));

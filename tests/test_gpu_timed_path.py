@@ -78,7 +78,7 @@ def test_mesh_scene_known_answers_at_1080p(scene_dir, monkeypatch):
 @pytest.mark.parametrize("name", ["pathtrace", "pt_uniform", "pt_env", "emitters", "one_sphere_emitter"])
 def test_gather_beside_shading_changes_nothing(name, scene_dir, repo_root, monkeypatch):
     """Path-traced frames run the gather of a generation on a second stream beside the next generation's shading
-    (RT_PAIR_GATHER=0: everything in turn).  Same rays, same counts; the image agrees to the order of a sample's float
+    (RT_PAIR_GATHER=0: everything in turn, 2: also for small batches).  Same rays, same counts; the image agrees to the order of a sample's float
     additions, and with the oracle to the bar of the timed path."""
     monkeypatch.setenv("RT_WIDE_NODES", "1")
     if name == "one_sphere_emitter":   # the benchmark scene in small: the shading kernel writes the emitter's shadow rays itself
@@ -89,7 +89,7 @@ def test_gather_beside_shading_changes_nothing(name, scene_dir, repo_root, monke
     ren = R.Renderer(sc)
     monkeypatch.setenv("RT_PAIR_GATHER", "0")
     img0, st0 = ren.render(cam)
-    monkeypatch.setenv("RT_PAIR_GATHER", "1")
+    monkeypatch.setenv("RT_PAIR_GATHER", "2")   # (by itself only for batches of 4 Mi slots and more)
     img1, st1 = ren.render(cam)
     img2, st2 = ren.render(cam)
     for st in (st1, st2):
