@@ -1048,8 +1048,8 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
         if (defer != 0 && L.type == RT_LIGHT_SPHERE) {
             const rt_sphere &sph = S.spheres[L.sphere];
             bool lit = false;
-            if (active && defer >= 2) {   // the shading kernel wrote the rays: ray i for vertex i
-                lit = Q.vis[shadow_base + vl] != 0.f;
+            if (defer >= 2) {   // the shading kernel wrote the rays, ray i for vertex i: the lanes that are here are those it reached
+                lit = active;
             } else if (active) {   // the ray of the block's lane 0 is on record, the block's rays are consecutive
                 const unsigned ri = record_index(shadow_base, vbase, (unsigned)k_pad, record_slot(light_of, slot_table, (unsigned)(k0 + kl), kl), 0u);
                 lit = Q.vis[__float_as_uint(((const float *)&Q.fd_ray[ri])[3]) + rec_lane] != 0.f;
@@ -1143,6 +1143,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         if (slot_scale < 0) c = scl(c, 0.004f);
         accum_add(W, slot_scale & 0x7fffffff, mul(mk(w.x, w.y, w.z), c));
     };
+
     auto evaluate = [&](unsigned n_ready) {   // the first n_ready (<= 64) collected vertices
         const bool on = lane < n_ready;
         const unsigned vl = mine[on ? lane : 0u];
@@ -1158,8 +1159,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const unsigned vl = vbase + lane;
         const bool valid = vl < nv;
         const unsigned v = shard_base + (valid ? vl : vbase);
-        const float4 af = defer == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : B.amb_first[v], w = B.weight[v];   // 3: as 2, and no ambient record was written
-        unsigned long long have = has_records ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
+        // defer 3: as 2, and the vertices have neither an ambient term nor a light-sample record: one the emitter's ray does
+        // not reach adds exactly nothing (its sum is throughput x 0), so all that is read of it is the ray's outcome
+        const bool lean = defer == 3;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 af = lean ? zero4 : B.amb_first[v], w = lean ? zero4 : B.weight[v];
+        unsigned long long have = has_records && !lean ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
         const bool room = record_index(shadow_base, vbase, (unsigned)k_pad, (unsigned)k_pad - 1u, 63u) < shadow_base + W.shadow_shard_entries;
         if (!room) {   // (light_setup_kernel has reported it; with the rays written by the shading kernel this is where it shows)
             have = 0;
@@ -1181,7 +1186,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
                 if (valid && W.shadow[gen & 1].vis[first_ray + lane] != 0.f) full = true;
             }
         }
-        if (valid && !full) finish(pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0), w, __float_as_int(B.kd_slot[v].w));
+        if (valid && !full && !lean) finish(pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0), w, __float_as_int(B.kd_slot[v].w));
         const unsigned long long mask = __ballot(full);
         if (mask) {
             const unsigned at = n_pending + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
