@@ -289,6 +289,12 @@ int rt_shard_owner_map(int32_t resx, int32_t resy, int32_t world, int32_t *owner
 int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample);
 uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples);
 
+/* Test hook: 1 when the scene's shadow rays are walked in any order.  A shadow ray (the any-hit case of bvh::intersect,
+ * src/bvh.cpp:383-480, as calculate_color uses it, src/ray_trace.cpp:232-241) gets the same answer in every order
+ * unless a surface can lie within the shadow-ray epsilon of a light sample; rt_scene_create decides that from the lights
+ * and the tree, and keeps the reference's order where it cannot rule it out (RT_ANY_ORDERED=1: always). */
+int32_t rt_scene_shadow_order_free(const rt_scene *scene);
+
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders
  * the rank's tiles into a packed tile-major buffer, moves the buffers to rank 0 in one grouped RCCL send / receive and,

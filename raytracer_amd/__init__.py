@@ -178,6 +178,12 @@ class Renderer:
         if rc != 0:
             raise RaytracerError(f"{what}: {self._g.rt_last_error().decode()}")
 
+    def shadow_order_free(self):
+        """True when the scene's shadow rays are walked in any order (rt_scene_shadow_order_free)."""
+        self._g.rt_scene_shadow_order_free.restype = C.c_int32
+        self._g.rt_scene_shadow_order_free.argtypes = [C.c_void_p]
+        return bool(self._g.rt_scene_shadow_order_free(self._ptr))
+
     def set_counters(self, enabled):
         self._check(self._g.rt_set_counters(self._ptr, 1 if enabled else 0), "rt_set_counters")
 

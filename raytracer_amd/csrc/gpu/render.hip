@@ -278,23 +278,35 @@ __device__ __forceinline__ void ray_result(const Wavefront &W, int gen, unsigned
 // WIDE: interior nodes are taken from the wide tree (four quantised boxes per 64-byte record, see wide_step) instead
 // of the two-box records.  The counting variants always walk the two-box records, whose visits are the reference's.
 // The any-hit walk of the wide tree gains from eight waves per SIMD where the closest-hit walk does best with six (4K /
-// 64 spp frame, closest / any hit: 6 waves 230.4 / 105.1 ms, 7 waves 232.3 / 103.4, 8 waves 236.1 / 101.9): it keeps eight
-// stack levels in LDS instead of eleven, which is what eight workgroups per CU leave room for.
+// 64 spp frame, closest / any hit: 6 waves 230.4 / 105.1 ms, 7 waves 232.3 / 103.4, 8 waves 236.1 / 101.9).  Its stack
+// entries are 4 bytes (wide_any_step), so the LDS share of eight workgroups per CU holds more levels of it than the closest-hit
+// walk's eleven -- which buys nothing (any hit with 8 / 12 / 15 levels: 93.6 / 93.8 / 92.8 ms); what is left of the share goes to
+// the top of the tree: 127 records instead of 63 (92.4 -> 91.4 ms; 191: 92.0; 255 records and 4 levels: 99.5).
 #ifndef RT_ANY_WAVES
 #define RT_ANY_WAVES 8
 #endif
 #ifndef RT_ANY_LDS_STACK
 #define RT_ANY_LDS_STACK 8
 #endif
-template <bool ANY, bool COUNT, bool WIDE>
+#ifndef RT_ANY_TOP_NODES
+#define RT_ANY_TOP_NODES 127
+#endif
+// FREE (any hit, wide): the scene's shadow rays get the same answer whatever the order of the walk (see
+// shadow_answers_order_free), so they take wide_any_step: slots in record order, 4-byte stack entries.
+template <bool ANY, bool COUNT, bool WIDE, bool FREE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ANY && WIDE ? RT_ANY_WAVES : RT_TRACE_WAVES, ANY && WIDE ? RT_ANY_WAVES : RT_TRACE_WAVES))) trace_kernel(DevScene S, Wavefront W, int gen, int whitted, TraceTuning tune, unsigned long long *__restrict__ stats) {
     static_assert(!(WIDE && COUNT), "the counters follow the two-box walk");
+    static_assert(!FREE || (ANY && WIDE), "only any-hit rays may walk in any order");
+    constexpr bool AW = FREE;   // the order-free any-hit walk of the wide tree: 4-byte stack entries
     constexpr int LEVELS = ANY && WIDE ? RT_ANY_LDS_STACK : LDS_STACK;   // stack entries in LDS
-    __shared__ uint2 stack_lds[LEVELS * 256];
-    __shared__ float4 top_nodes[TOP_NODES > 0 ? 4 * TOP_NODES : 1];
+    __shared__ uint2 stack_lds[AW ? (LEVELS + 1) / 2 * 256 : LEVELS * 256];
+    constexpr int TOP = AW ? RT_ANY_TOP_NODES : TOP_NODES;   // records of the tree's top in LDS (4-byte entries leave room for more)
+    __shared__ float4 top_nodes[TOP > 0 ? 4 * TOP : 1];
     uint2 *lds = stack_lds + threadIdx.x;
-    uint2 spill[64 - LEVELS];
-    const int n_top = TOP_NODES > 0 ? min(WIDE ? S.n_wtop : S.n_top, TOP_NODES) : 0;
+    unsigned *lds_any = (unsigned *)stack_lds + threadIdx.x;
+    uint2 spill[AW ? (64 - LEVELS + 1) / 2 : 64 - LEVELS];
+    unsigned *spill_any = (unsigned *)spill;
+    const int n_top = TOP > 0 ? min(WIDE ? S.n_wtop : S.n_top, TOP) : 0;
     {
         const float4 *records = WIDE ? S.wnodes : S.nodes;
         for (int i = threadIdx.x; i < 4 * n_top; i += 256) top_nodes[i] = records[i];
@@ -398,7 +410,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ANY &&
             run_pop = n_pop >= tune.pop_min || __ballot(r.cur != REF_POP && r.cur != REF_IDLE) == 0;
         }
         if (run_pop && r.cur == REF_POP) {
-            if (!stack_pop<(!ANY || COUNT), COUNT, LEVELS>(r, lds, spill, c)) {
+            if (!(AW ? pop_any<LEVELS>(r, lds_any, spill_any) : stack_pop<(!ANY || COUNT), COUNT, LEVELS>(r, lds, spill, c))) {
                 ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                 r.cur = REF_IDLE;
             }
@@ -415,9 +427,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ANY &&
         if (run_node) {
             if ((unsigned)r.cur < (unsigned)REF_POP) {
                 if (WIDE) {
-                    wide_step<LEVELS>(S, r, lds, spill, top_nodes, n_top);
+                    if (AW)
+                        wide_any_step<LEVELS>(S, r, lds_any, spill_any, top_nodes, n_top);
+                    else
+                        wide_step<LEVELS>(S, r, lds, spill, top_nodes, n_top);
 #ifndef RT_NO_INLINE_POP
-                    if (r.cur == REF_POP && pop_inline<!ANY, LEVELS>(r, lds)) {
+                    if (r.cur == REF_POP && (AW ? pop_any_inline<LEVELS>(r, lds_any) : pop_inline<!ANY, LEVELS>(r, lds))) {
                         ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                         r.cur = REF_IDLE;
                     }
@@ -472,7 +487,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ANY &&
                 }
 #ifndef RT_NO_INLINE_POP
                 if (WIDE && r.cur == REF_POP) {
-                    if (pop_inline<!ANY, LEVELS>(r, lds)) {
+                    if (AW ? pop_any_inline<LEVELS>(r, lds_any) : pop_inline<!ANY, LEVELS>(r, lds)) {
                         ray_result<ANY>(W, gen, idx, r.t, r.prim, dist, eps);
                         r.cur = REF_IDLE;
                     }
@@ -1330,7 +1345,8 @@ struct rt_scene {
     size_t owned_room = 0;
     int owned_key[4] = {0, 0, 0, 0};  // resx, resy, rank, world the list was built for
     int n_owned = 0;
-    unsigned trace_blocks[2][3] = {{0, 0, 0}, {0, 0, 0}};   // resident workgroups of trace_kernel<ANY, ...> (plain, counting, wide), a multiple of N_SHARDS
+    unsigned trace_blocks[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // resident workgroups of trace_kernel<ANY, ...> (plain, counting, wide, wide in any order), a multiple of N_SHARDS
+    bool shadow_order_free = false;   // see shadow_answers_order_free
     // per-kernel timing (rt_set_profiling): every launch bracketed by two events on `stream`
     bool profiling = false;
     std::vector<hipEvent_t> event_pool;
@@ -1535,10 +1551,12 @@ static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned gri
     // the wide tree, once built, serves every render without counters
     const bool wide = !count && s->dev.wnodes != nullptr;
     typedef void (*TraceFn)(DevScene, Wavefront, int, int, TraceTuning, unsigned long long *);
-    const TraceFn fn = wide    ? (any ? trace_kernel<true, false, true> : trace_kernel<false, false, true>)
+    const bool order_free = wide && any && s->shadow_order_free;
+    const TraceFn fn = order_free ? trace_kernel<true, false, true, true>
+                       : wide  ? (any ? trace_kernel<true, false, true> : trace_kernel<false, false, true>)
                        : count ? (any ? trace_kernel<true, true, false> : trace_kernel<false, true, false>)
                                : (any ? trace_kernel<true, false, false> : trace_kernel<false, false, false>);
-    unsigned &blocks = s->trace_blocks[any][wide ? 2 : (count ? 1 : 0)];
+    unsigned &blocks = s->trace_blocks[any][order_free ? 3 : (wide ? 2 : (count ? 1 : 0))];
     if (!blocks) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
@@ -1558,6 +1576,78 @@ static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned gri
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, s->dev, s->wf, gen, whitted, tune, s->stats);
 }
 
+// Does the answer of the scene's shadow rays depend on the order in which a ray's walk looks at the leaves?  A shadow ray
+// ends with the first hit before the light sample (t < dist), and counts as shadow when that hit lies more than the
+// shadow-ray epsilon before it (t < dist - epsilon, src/ray_trace.cpp:232-241).  If every hit a ray can find is of the
+// second kind, "some hit exists" decides, whatever is found first; if a surface can lie within epsilon of the sample -- an
+// emitter's own triangle, on which its samples sit -- the answer depends on whether that surface or a real occluder is
+// found first, and only the reference's order gives the reference's answer.  So: true when no leaf of the tree that
+// comes within reach of a light's sample positions (a point for point, spot and sphere lights -- every sample of a sphere
+// light aims at its centre, src/lights.cpp:418-422 --, a parallelogram for area lights; directional and environment lights
+// end at no surface) holds a triangle, and the spheres in such leaves keep their surface away from the point.  Planes are
+// tested before the tree by every walk.  Conservative: a scene that fails keeps the ordered walk.
+static bool shadow_answers_order_free(const rt_scene_desc *d) {
+    if (!d->bvh_nodes || d->n_bvh_nodes < 1 || !d->bvh_prims) return false;
+    const float eps = std::fabs(d->shadow_ray_epsilon);
+    for (int li = 0; li < d->n_lights; ++li) {
+        const rt_light &L = d->lights[li];
+        float lo[3], hi[3];
+        bool point = true;
+        if (L.type == RT_LIGHT_DIRECTIONAL || L.type == RT_LIGHT_ENV) continue;
+        if (L.type == RT_LIGHT_TRIANGLE) return false;
+        if (L.type == RT_LIGHT_POINT || L.type == RT_LIGHT_SPOT) {
+            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = L.position[a];
+        } else if (L.type == RT_LIGHT_SPHERE) {
+            if (L.sphere < 0 || L.sphere >= d->n_spheres) return false;
+            const float *m = d->spheres[L.sphere].model;   // the sample position: model * (0, 0, 0, 1)
+            for (int a = 0; a < 3; ++a) lo[a] = hi[a] = m[4 * a + 3];
+        } else if (L.type == RT_LIGHT_AREA) {
+            point = false;
+            for (int a = 0; a < 3; ++a) {
+                const float r = 0.5f * std::fabs(L.size) * (std::fabs(L.u[a]) + std::fabs(L.v[a]));
+                lo[a] = L.position[a] - r, hi[a] = L.position[a] + r;
+            }
+        } else {
+            return false;
+        }
+        float reach = 0.f;
+        for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+        reach = 4.0f * eps + 1e-4f * reach + 1e-3f;   // epsilon, rounding of the distances, padding of the boxes
+        if (!std::isfinite(reach)) return false;
+        std::vector<int> todo{0};
+        while (!todo.empty()) {
+            const int i = todo.back();
+            todo.pop_back();
+            const rt_bvh_node &n = d->bvh_nodes[i];
+            bool apart = false;
+            for (int a = 0; a < 3; ++a) apart |= !(n.bmin[a] <= hi[a] + reach && n.bmax[a] >= lo[a] - reach);   // (a box that is not a number is not apart)
+            if (apart) continue;
+            if (n.n_prims == 0) {
+                todo.push_back(i + 1);
+                todo.push_back(n.offset);
+                continue;
+            }
+            for (int k = 0; k < n.n_prims; ++k) {
+                const rt_bvh_prim &pr = d->bvh_prims[n.offset + k];
+                if (pr.shape < d->n_triangles || !point) return false;
+                // a sphere: distance of the point from its surface, in its own space, brought to the world by the least
+                // stretch of its transform (1 / Frobenius norm of the inverse bounds that from below)
+                const rt_sphere &sp = d->spheres[pr.shape - d->n_triangles];
+                const float *im = sp.inv_model;
+                float q[3], norm2 = 0.f, off2 = 0.f;
+                for (int r = 0; r < 3; ++r) {
+                    q[r] = im[4 * r] * lo[0] + im[4 * r + 1] * lo[1] + im[4 * r + 2] * lo[2] + im[4 * r + 3];
+                    for (int c = 0; c < 3; ++c) norm2 += im[4 * r + c] * im[4 * r + c];
+                    off2 += (q[r] - sp.center[r]) * (q[r] - sp.center[r]);
+                }
+                const float from_surface = std::fabs(std::sqrt(off2) - sp.radius) / std::sqrt(norm2);
+                if (!(from_surface > reach)) return false;
+            }
+        }
+    }
+    return true;
+}
+
 // Builds and uploads the wide tree from the kept copy of the BVH (which is released either way).  A tree that does not
 // qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
 static int build_wide_tree(rt_scene *s) {
@@ -1566,7 +1656,7 @@ static int build_wide_tree(rt_scene *s) {
     if (nodes.empty()) return 0;
     std::vector<WideRecord> records;   // 64 bytes each, read as 4 x float4 on the device
     int root_ref = 0, n_top = 0;
-    if (!build_wide_nodes(nodes.data(), (int)nodes.size(), TOP_NODES, LDS_STACK + SPILL_STACK, records, root_ref, n_top)) return 0;
+    if (!build_wide_nodes(nodes.data(), (int)nodes.size(), std::max(TOP_NODES, RT_ANY_TOP_NODES), LDS_STACK + SPILL_STACK, records, root_ref, n_top)) return 0;
     static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
     float4 *dev = nullptr;
     HIP_OK(hipSetDevice(s->device));
@@ -1964,6 +2054,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             s->only_regular_materials &= d->materials[i].type == RT_MAT_REGULAR;
         }
         s->single_sphere_emitter = d->n_lights == 1 && d->lights[0].type == RT_LIGHT_SPHERE && d->lights[0].samples <= 64;
+        s->shadow_order_free = !(getenv("RT_ANY_ORDERED") && atoi(getenv("RT_ANY_ORDERED")) != 0) && shadow_answers_order_free(d);
     }
     *out = s;
     return 0;
@@ -2452,6 +2543,7 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *
 
 int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample) { return queue_shard_of(group_of_sample, sample); }
 uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { return max_shard_groups(groups_per_sample, samples); }
+int32_t rt_scene_shadow_order_free(const rt_scene *s) { return s && s->shadow_order_free ? 1 : 0; }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major
 // order, which is the order of its packed buffer.

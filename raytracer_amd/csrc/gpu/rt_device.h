@@ -326,6 +326,97 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
     r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 
+// ---- the any-hit walk of the wide tree -------------------------------------------------------------------------------
+// A ray that only asks whether anything is hit gets the same answer whatever the order of its walk: the answer is "some
+// leaf whose own exact box the ray passes holds an entry the ray hits", and which leaves are reached does not depend on the
+// order either (such a ray never shortens).  So its step leaves the slots in the order of the record -- no sign tests, no
+// byte permutation, no reordering of the refs -- and its stack holds the references alone, 4 bytes an entry: whatever
+// was pushed still qualifies when it is popped.  (4K / 64 spp frame, any hit: 102.4 -> 96.9 ms with the slots unsorted.)
+template <int LEVELS>
+__device__ __forceinline__ bool pop_any(RayState &r, const unsigned *lds, const unsigned *spill) {
+    if (r.sp == 0) return false;
+    --r.sp;
+    if (r.sp < LEVELS) {
+        r.cur = (int)lds[r.sp * STACK_STRIDE];
+    } else {
+        r.cur = (int)((const volatile unsigned *)spill)[r.sp - LEVELS];
+    }
+    return true;
+}
+// (as pop_inline: the top entry when it lies in LDS; true when the stack was empty)
+template <int LEVELS>
+__device__ __forceinline__ bool pop_any_inline(RayState &r, const unsigned *lds) {
+    if (r.sp == 0) return true;
+    if (r.sp <= LEVELS) {
+        --r.sp;
+        r.cur = (int)lds[r.sp * STACK_STRIDE];
+    }
+    return false;
+}
+template <int LEVELS>
+__device__ __forceinline__ void wide_any_step(const DevScene &S, RayState &r, unsigned *lds, unsigned *spill, const float4 *top, int n_top) {
+    float4 n0, n1, n2, n3;
+    if (r.cur < n_top) {
+        const float4 *np = top + 4 * r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        asm volatile("" ::: );   // (keeps the LDS reads apart from the global loads, see wide_step)
+    } else {
+        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    }
+    const unsigned head = __float_as_uint(n0.w);
+    const float sx = __uint_as_float(head & 0x7f800000u), sy = n3.z, sz = n3.w;
+    const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
+    const unsigned qlx = __float_as_uint(n2.x), qhx = __float_as_uint(n2.y), qly = __float_as_uint(n2.z), qhy = __float_as_uint(n2.w);
+    const unsigned qlz = __float_as_uint(n3.x), qhz = __float_as_uint(n3.y);
+    const unsigned ex = nx ? qhx : qlx, fx = nx ? qlx : qhx, ey = ny ? qhy : qly, fy = ny ? qly : qhy, ez = nz ? qhz : qlz, fz = nz ? qlz : qhz;
+    // the arithmetic of wide_step, slot by slot: ((origin + q * 2^e) - o) * (1 / d)
+#define RT_WIDE_AXIS(q, s, p, o, inv, A, B)                                   \
+    const f2 A = (fma2(f2{ubyte_f(q, 0), ubyte_f(q, 1)}, s, p) - o) * inv;   \
+    const f2 B = (fma2(f2{ubyte_f(q, 2), ubyte_f(q, 3)}, s, p) - o) * inv;
+    RT_WIDE_AXIS(ex, sx, n0.x, r.ox, r.ix, ex01, ex23)
+    RT_WIDE_AXIS(fx, sx, n0.x, r.ox, r.ix, fx01, fx23)
+    RT_WIDE_AXIS(ey, sy, n0.y, r.oy, r.iy, ey01, ey23)
+    RT_WIDE_AXIS(fy, sy, n0.y, r.oy, r.iy, fy01, fy23)
+    RT_WIDE_AXIS(ez, sz, n0.z, r.oz, r.iz, ez01, ez23)
+    RT_WIDE_AXIS(fz, sz, n0.z, r.oz, r.iz, fz01, fz23)
+#undef RT_WIDE_AXIS
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(ex01.x, ey01.x), ez01.x), m0 = __builtin_fminf(__builtin_fminf(fx01.x, fy01.x), fz01.x);
+    const float t1 = __builtin_fmaxf(__builtin_fmaxf(ex01.y, ey01.y), ez01.y), m1 = __builtin_fminf(__builtin_fminf(fx01.y, fy01.y), fz01.y);
+    const float t2 = __builtin_fmaxf(__builtin_fmaxf(ex23.x, ey23.x), ez23.x), m2 = __builtin_fminf(__builtin_fminf(fx23.x, fy23.x), fz23.x);
+    const float t3 = __builtin_fmaxf(__builtin_fmaxf(ex23.y, ey23.y), ez23.y), m3 = __builtin_fminf(__builtin_fminf(fx23.y, fy23.y), fz23.y);
+    const int d0 = __float_as_int(n1.x), d1 = __float_as_int(n1.y), d2 = __float_as_int(n1.z), d3 = __float_as_int(n1.w);
+    const bool h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < r.t);
+    const bool h1 = (t1 <= m1) & (m1 > 0.0f) & (t1 < r.t);
+    const bool h2 = (t2 <= m2) & (m2 > 0.0f) & (t2 < r.t);
+    const bool h3 = (t3 <= m3) & (m3 > 0.0f) & (t3 < r.t);
+    // the first slot that passes is next; the others wait on the stack
+    const bool p3 = h3 & (h0 | h1 | h2), p2 = h2 & (h0 | h1), p1 = h1 & h0;
+    if (r.sp + 3 <= LEVELS) {   // all in LDS: store without branching, an entry above the top is never read
+        int sp = r.sp;
+        lds[sp * STACK_STRIDE] = (unsigned)d3;
+        sp += p3 ? 1 : 0;
+        lds[sp * STACK_STRIDE] = (unsigned)d2;
+        sp += p2 ? 1 : 0;
+        lds[sp * STACK_STRIDE] = (unsigned)d1;
+        sp += p1 ? 1 : 0;
+        r.sp = sp;
+    } else {
+        const int refs[3] = {d3, d2, d1};
+        const bool push[3] = {p3, p2, p1};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!push[k] || r.sp >= 64) continue;   // (deeper than 64 would have overrun the reference's own stack)
+            if (r.sp < LEVELS)
+                lds[r.sp * STACK_STRIDE] = (unsigned)refs[k];
+            else
+                ((volatile unsigned *)spill)[r.sp - LEVELS] = (unsigned)refs[k];
+            ++r.sp;
+        }
+    }
+    r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
+}
+
 // Pops until an entry whose box still starts before the closest hit; false when the stack is empty.  With
 // CHECK false (an any-hit ray never shortens, so every pushed entry still qualifies) the first entry is taken.
 template <bool CHECK, bool COUNT, int LEVELS = LDS_STACK>

@@ -90,3 +90,56 @@ def test_full_size_frame_same_on_both_walks(scene_dir, monkeypatch):
     assert (st_w.primary_rays, st_w.secondary_rays) == (st_2.primary_rays, st_2.secondary_rays) and st_w.primary_rays == 3840 * 2160 * 16
     err = np.abs(img_w - img_2) / np.maximum(np.abs(img_2), 1 / 255)
     assert err.max() <= 1e-5
+
+
+def test_shadow_rays_in_any_order_only_where_the_order_cannot_matter(scene_dir, repo_root, monkeypatch, tmp_path):
+    """A shadow ray ends with the first hit before the light sample and counts as shadow when that hit lies more than the
+    shadow-ray epsilon before it (src/ray_trace.cpp:232-241): the order of the walk matters exactly when a surface can lie
+    within epsilon of a sample.  Scenes whose lights hang free of the geometry walk their shadow rays in record order;
+    emitters made of triangles (their samples sit on them) and a point light on a wall keep the reference's order."""
+    import json
+    import os
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    from test_oracle_vs_reference import scene_path
+    # (pt_uniform: its sphere light is placed by its centre, not by a transformation, so its samples aim at model * origin =
+    # the world's origin (src/lights.cpp:418-422), which lies on the ground mesh)
+    free = {"simple": True, "brdfs": True, "distributed": True, "pt_uniform": False, "emitters": False, "pathtrace": False}
+    for name, want in free.items():
+        ren = R.Renderer(R.Scene(scene_path(name, scene_dir, repo_root)))
+        assert ren.shadow_order_free() == want, name
+    small = R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt_order", n=48, width=96, height=54, spp=16))
+    assert R.Renderer(small).shadow_order_free()          # a sphere emitter: every sample aims at its centre, deep inside it
+    textured = R.Scene(scenegen.write_textured_scene(scene_dir + "/tex_order", n=24, width=96, height=54, spp=4))
+    assert R.Renderer(textured).shadow_order_free()       # area lights above the scene
+    doc = json.load(open(os.path.join(repo_root, "scenes", "simple.json")))
+    verts = [float(x) for x in doc["Scene"]["VertexData"]["_data"].split()] if isinstance(doc["Scene"]["VertexData"], dict) else [float(x) for x in doc["Scene"]["VertexData"].split()]
+    lights = doc["Scene"]["Lights"]["PointLight"]
+    first = lights[0] if isinstance(lights, list) else lights
+    first["Position"] = " ".join(f"{v:.6f}" for v in verts[0:3])   # on a vertex of the mesh
+    path = str(tmp_path / "light_on_wall.json")
+    json.dump(doc, open(path, "w"))
+    assert not R.Renderer(R.Scene(path)).shadow_order_free()
+
+
+@pytest.mark.parametrize("name", ["simple", "brdfs", "distributed", "one_sphere_emitter", "textured"])
+def test_shadow_rays_in_any_order_give_the_same_image(name, scene_dir, repo_root, monkeypatch):
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    from test_oracle_vs_reference import scene_path
+    if name == "one_sphere_emitter":
+        path = scenegen.write_path_traced_scene(scene_dir + "/pt_order", n=48, width=96, height=54, spp=16)
+    elif name == "textured":
+        path = scenegen.write_textured_scene(scene_dir + "/tex_order", n=24, width=96, height=54, spp=4)
+    else:
+        path = scene_path(name, scene_dir, repo_root)
+    monkeypatch.setenv("RT_PAIR_GATHER", "0")
+    monkeypatch.setenv("RT_ANY_ORDERED", "1")
+    sc = R.Scene(path)
+    ordered = R.Renderer(sc)
+    assert not ordered.shadow_order_free()
+    img0, st0 = ordered.render(sc.camera(0))
+    monkeypatch.setenv("RT_ANY_ORDERED", "0")
+    free = R.Renderer(sc)
+    assert free.shadow_order_free()
+    img1, st1 = free.render(sc.camera(0))
+    assert np.array_equal(img0, img1), "a shadow ray's answer changed with the order of its walk"
+    assert (st0.shadow_rays, st0.shadow_rays_traced, st0.secondary_rays) == (st1.shadow_rays, st1.shadow_rays_traced, st1.secondary_rays)
