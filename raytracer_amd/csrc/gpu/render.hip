@@ -1620,7 +1620,7 @@ static bool shadow_answers_order_free(const rt_scene_desc *d) {
             todo.pop_back();
             const rt_bvh_node &n = d->bvh_nodes[i];
             bool apart = false;
-            for (int a = 0; a < 3; ++a) apart |= !(n.bmin[a] <= hi[a] + reach && n.bmax[a] >= lo[a] - reach);   // (a box that is not a number is not apart)
+            for (int a = 0; a < 3; ++a) apart |= n.bmin[a] > hi[a] + reach || n.bmax[a] < lo[a] - reach;   // (a box that is not a number is not apart)
             if (apart) continue;
             if (n.n_prims == 0) {
                 todo.push_back(i + 1);
