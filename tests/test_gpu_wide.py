@@ -83,6 +83,7 @@ def test_full_size_frame_same_on_both_walks(scene_dir, monkeypatch):
     sc = R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt1m_4k", width=3840, height=2160, spp=16))
     cam = sc.camera(0)
     ren = R.Renderer(sc)
+    assert ren.shadow_order_free()   # (so the first render's shadow rays walk in record order, the second's in the reference's)
     img_w, st_w = ren.render(cam)
     ren.set_counters(True)
     img_2, st_2 = ren.render(cam)
