@@ -122,16 +122,20 @@ def test_shadow_rays_in_any_order_only_where_the_order_cannot_matter(scene_dir, 
     assert not R.Renderer(R.Scene(path)).shadow_order_free()
 
 
-@pytest.mark.parametrize("name", ["simple", "brdfs", "distributed", "one_sphere_emitter", "textured"])
+@pytest.mark.parametrize("name", ["simple", "mesh70k", "one_sphere_emitter", "textured_generated"] + sorted(GS.SCENES))
 def test_shadow_rays_in_any_order_give_the_same_image(name, scene_dir, repo_root, monkeypatch):
+    """Every scene whose shadow rays are walked in record order, against the same scene with the reference's order
+    forced: the same image bit for bit (deterministic scenes and stochastic ones alike: same rays, same answers)."""
     monkeypatch.setenv("RT_WIDE_NODES", "1")
     from test_oracle_vs_reference import scene_path
     if name == "one_sphere_emitter":
         path = scenegen.write_path_traced_scene(scene_dir + "/pt_order", n=48, width=96, height=54, spp=16)
-    elif name == "textured":
+    elif name == "textured_generated":
         path = scenegen.write_textured_scene(scene_dir + "/tex_order", n=24, width=96, height=54, spp=4)
     else:
         path = scene_path(name, scene_dir, repo_root)
+    if name in ("emitters", "pathtrace", "pt_uniform"):
+        pytest.skip("a surface lies within the shadow-ray epsilon of this scene's light samples: it keeps the reference's order")
     monkeypatch.setenv("RT_PAIR_GATHER", "0")
     monkeypatch.setenv("RT_ANY_ORDERED", "1")
     sc = R.Scene(path)
