@@ -294,6 +294,8 @@ uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples);
  * unless a surface can lie within the shadow-ray epsilon of a light sample; rt_scene_create decides that from the lights
  * and the tree, and keeps the reference's order where it cannot rule it out (RT_ANY_ORDERED=1: always). */
 int32_t rt_scene_shadow_order_free(const rt_scene *scene);
+/* The same decision from a scene description alone (host only, no GPU needed; RT_ANY_ORDERED is not consulted). */
+int32_t rt_shadow_order_free(const rt_scene_desc *desc);
 
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders

@@ -2544,6 +2544,7 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *
 int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample) { return queue_shard_of(group_of_sample, sample); }
 uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { return max_shard_groups(groups_per_sample, samples); }
 int32_t rt_scene_shadow_order_free(const rt_scene *s) { return s && s->shadow_order_free ? 1 : 0; }
+int32_t rt_shadow_order_free(const rt_scene_desc *d) { return d && d->abi_version == RT_ABI_VERSION && shadow_answers_order_free(d) ? 1 : 0; }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major
 // order, which is the order of its packed buffer.
