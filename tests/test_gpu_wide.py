@@ -125,7 +125,8 @@ def test_shadow_rays_in_any_order_only_where_the_order_cannot_matter(scene_dir, 
 @pytest.mark.parametrize("name", ["simple", "mesh70k", "one_sphere_emitter", "textured_generated"] + sorted(GS.SCENES))
 def test_shadow_rays_in_any_order_give_the_same_image(name, scene_dir, repo_root, monkeypatch):
     """Every scene whose shadow rays are walked in record order, against the same scene with the reference's order
-    forced: the same image bit for bit (deterministic scenes and stochastic ones alike: same rays, same answers)."""
+    forced: the same image (bit for bit where no path splits; deterministic scenes and stochastic ones alike: same rays,
+    same answers)."""
     monkeypatch.setenv("RT_WIDE_NODES", "1")
     from test_oracle_vs_reference import scene_path
     if name == "one_sphere_emitter":
@@ -146,5 +147,10 @@ def test_shadow_rays_in_any_order_give_the_same_image(name, scene_dir, repo_root
     free = R.Renderer(sc)
     assert free.shadow_order_free()
     img1, st1 = free.render(sc.camera(0))
-    assert np.array_equal(img0, img1), "a shadow ray's answer changed with the order of its walk"
+    # a flipped answer moves a pixel by a light sample's contribution; the order of a sample's float additions (paths that
+    # split at a dielectric add to one sample from two lanes, in arrival order) by an ulp or two
+    err = np.abs(img0 - img1) / np.maximum(np.abs(img0), 1.0 / 255.0)
+    assert err.max() <= 2e-6, "a shadow ray's answer changed with the order of its walk"
+    if name in ("simple", "mesh70k", "brdfs", "distributed", "textured_generated", "one_sphere_emitter"):   # no path splits
+        assert np.array_equal(img0, img1)
     assert (st0.shadow_rays, st0.shadow_rays_traced, st0.secondary_rays) == (st1.shadow_rays, st1.shadow_rays_traced, st1.secondary_rays)
