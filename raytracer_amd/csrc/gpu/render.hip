@@ -65,9 +65,11 @@ thread_local std::string g_error;
 // waves per SIMD of the trace kernel, measured (closest-hit time per 4K / 64 spp frame of the 1M-triangle scene).  With the
 // two-box records 5 was fastest (4: 475 ms, 5: 426, 6: 438, 7: 459, 8: 467: more waves evict each other's part of the tree
 // from the caches); the wide tree moves less data per ray and gains from a sixth wave (4: 307 ms, 5: 273, 6: 255), which
-// is what 82 registers and 26 KB of LDS per workgroup (stack 22 KB + top of the tree 4 KB) allow
+// is what 82 registers and 26 KB of LDS per workgroup (stack 22 KB + top of the tree 4 KB) allow.  A seventh (72 registers, no
+// spills; ten stack levels and 31 top records in LDS: 22 KB per workgroup) pays a little once the steps of an iteration share
+// it: four alternating runs 228.9 - 230.2 ms against 225.4 - 226.3 (with 63 top records and nine levels 228.1, no gain).
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 6
+#define RT_TRACE_WAVES 7
 #endif
 // Queue generations a batch can have: path depths 0 .. ceil(MaxRecursionDepth), plus the children the last one appends.
 // The depth travels in 16 bits of a path record; the append counters are allocated for what the scene asks for.

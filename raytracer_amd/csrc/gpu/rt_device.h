@@ -96,7 +96,7 @@ struct Hit {
 //   REF_POP              take the next node from the stack
 //   REF_IDLE             no ray
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 11
+#define RT_LDS_STACK 10
 #endif
 constexpr int LDS_STACK = RT_LDS_STACK;
 constexpr int SPILL_STACK = 64 - LDS_STACK;   // LDS_STACK + SPILL_STACK = 64 = the reference's stack size (src/bvh.cpp:423)
@@ -209,12 +209,13 @@ __device__ __forceinline__ void stack_push(RayState &r, uint2 *lds, uint2 *spill
 // One interior node: both child boxes, near child next, far child pushed.  `lds` is this lane's column of a
 // __shared__ uint2 array laid out [LDS_STACK][STACK_STRIDE].
 #ifndef RT_TOP_NODES
-#define RT_TOP_NODES 63
+#define RT_TOP_NODES 31
 #endif
 constexpr int TOP_NODES = RT_TOP_NODES;   // node records a workgroup of the trace kernel keeps in LDS (0: none).  Measured with the
 // two-box records, closest-hit time of a 4K / 64 spp frame: none 384 ms, 31: 379, 63: 375, 127 or more: 369.  LDS is what limits
 // the workgroups per CU: stack (2 KB per level) plus these records (64 bytes each) stay under 26.6 KB for six workgroups; with
-// the wide tree 11 levels + 63 records and 10 levels + 95 records measure the same (255 ms), 9 levels + 127 records 262 ms
+// the wide tree 11 levels + 63 records and 10 levels + 95 records measure the same (255 ms), 9 levels + 127 records 262 ms.
+// Seven workgroups per CU (the closest-hit walk's default since) leave 22.8 KB each: 10 levels + 31 records.
 
 // `top`: the workgroup's LDS copy of the first `n_top` node records (the top levels of the tree, which every ray walks);
 // records read from it do not go through the vector cache, whose lookups are what bounds the traversal.
