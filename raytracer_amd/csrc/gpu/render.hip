@@ -818,22 +818,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                     *W.overflow = 1u;
                 } else {
                     const unsigned vi = shard_base + vl;
-                    W.vtx[gen & 1].p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
-                    W.vtx[gen & 1].n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
                     const rt_material &vm = S.materials[v_mat];
-                    W.vtx[gen & 1].view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
-                    W.vtx[gen & 1].kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot | (v_scale != 1.0f ? (int)0x80000000 : 0)));
-                    W.vtx[gen & 1].ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
-                    W.vtx[gen & 1].weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
-                    // (path tracing has no ambient term, and with the emitter's ray written here no sample has a record: the
-                    // gather kernel is told not to read this record, defer = 3)
-                    if (!(PT && emitter_rays)) W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
+                    const int slot_scale = slot | (v_scale != 1.0f ? (int)0x80000000 : 0);
+                    V ldir = mk(0, 0, 0);
+                    float dist = 0.f, d2 = 1.f;
+                    if (emitter_rays) sphere_light_geometry(S.spheres[S.lights[0].sphere], v_p, ldir, dist, d2);
+                    if (PT && emitter_rays) {
+                        // Path tracing under one sphere emitter (gather mode 3): no ambient term, no light-sample records, and the
+                        // direction to the emitter does not depend on the sample -- so what the gather needs of the vertex is the
+                        // BRDF's two factors for that direction, the squared distance, the path's weight, key and slot: 48 bytes
+                        // instead of 96 (the direction itself is in the shadow ray below).  Same functions on the same inputs as the
+                        // gather would call: the same bits.
+                        V f_d, f_s;
+                        brdf_terms(brdf_code(vm), vm.phong_exponent, v_n, ldir, v_view, v_kd, v_ks, f_d, f_s);
+                        W.vtx[gen & 1].n_key[vi] = make_float4(f_d.x, f_d.y, f_d.z, __uint_as_float(key));
+                        W.vtx[gen & 1].view_mat[vi] = make_float4(f_s.x, f_s.y, f_s.z, d2);
+                        W.vtx[gen & 1].kd_slot[vi] = make_float4(v_w.x, v_w.y, v_w.z, __int_as_float(slot_scale));
+                    } else {
+                        W.vtx[gen & 1].p_time[vi] = make_float4(v_p.x, v_p.y, v_p.z, time);
+                        W.vtx[gen & 1].n_key[vi] = make_float4(v_n.x, v_n.y, v_n.z, __uint_as_float(key));
+                        W.vtx[gen & 1].view_mat[vi] = make_float4(v_view.x, v_view.y, v_view.z, __int_as_float(brdf_code(vm)));
+                        W.vtx[gen & 1].kd_slot[vi] = make_float4(v_kd.x, v_kd.y, v_kd.z, __int_as_float(slot_scale));
+                        W.vtx[gen & 1].ks_n[vi] = make_float4(v_ks.x, v_ks.y, v_ks.z, vm.phong_exponent);
+                        W.vtx[gen & 1].weight[vi] = make_float4(v_w.x, v_w.y, v_w.z, 0.f);
+                        W.vtx[gen & 1].amb_first[vi] = make_float4(v_amb.x, v_amb.y, v_amb.z, 0.f);
+                    }
                     if (emitter_rays) {
                         // The scene's only light is one sphere emitter, whose samples share one shadow ray per vertex (see
                         // light_setup_kernel): the ray is written here, ray i for vertex i, and no set-up pass runs.
-                        V ldir;
-                        float dist, d2;
-                        sphere_light_geometry(S.spheres[S.lights[0].sphere], v_p, ldir, dist, d2);
                         const V so = add(v_p, scl(ldir, S.seps));
                         const unsigned ri = shard * W.shadow_shard_entries + vl;
                         if (vl < W.shadow_shard_entries) {
@@ -1136,6 +1148,48 @@ __device__ __forceinline__ V gather_vertex(const DevScene &S, const Wavefront &W
     return c;
 }
 
+// The evaluation for gather mode 3 (path tracing under one sphere emitter, see shade_kernel): the vertex record holds the
+// BRDF's factors for the emitter's direction, the squared distance and the path's weight; the direction is the shadow ray's.
+// The sample loop is gather_vertex's.
+__device__ __forceinline__ V gather_lean(const DevScene &S, bool lit, V f_d, V f_s, V ldir, float d2, uint32_t key, Counters &cnt) {
+    const rt_light &L = S.lights[0];
+    const SphereEmitter E = sphere_emitter(L, S.spheres[L.sphere]);
+    const float lw = rt_div(1.0f, (float)L.samples);
+    V c = mk(0, 0, 0);
+    int ks = 0;
+    for (; ks + 1 < L.samples; ks += 2) {
+        if (!lit) continue;
+        const unsigned k = (unsigned)ks;
+        const f2 r1 = f2{rnd(key, DIM_LIGHT + 2 * k), rnd(key, DIM_LIGHT + 2 * k + 2)};
+        const f2 r2 = f2{rnd(key, DIM_LIGHT + 2 * k + 1), rnd(key, DIM_LIGHT + 2 * k + 3)};
+        f2 rx, ry, rz;
+        sphere_light_radiance2(E, ldir, d2, r1, r2, rx, ry, rz);
+        const f2 dx = (f_d.x * rx) * lw, dy = (f_d.y * ry) * lw, dz = (f_d.z * rz) * lw;
+        const f2 sx = (f_s.x * rx) * lw, sy = (f_s.y * ry) * lw, sz = (f_s.z * rz) * lw;
+        if (!(rx.x == 0 && ry.x == 0 && rz.x == 0)) {
+            ++cnt.shadow;
+            c = add(c, mk(dx.x, dy.x, dz.x));
+            c = add(c, mk(sx.x, sy.x, sz.x));
+        }
+        if (!(rx.y == 0 && ry.y == 0 && rz.y == 0)) {
+            ++cnt.shadow;
+            c = add(c, mk(dx.y, dy.y, dz.y));
+            c = add(c, mk(sx.y, sy.y, sz.y));
+        }
+    }
+    for (; ks < L.samples; ++ks) {   // an odd sample count's last one
+        if (!lit) continue;
+        const unsigned k = (unsigned)ks;
+        const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
+        const V rad = sphere_light_radiance(L, S.spheres[L.sphere], ldir, d2, r1, r2);
+        if (rad.x == 0 && rad.y == 0 && rad.z == 0) continue;
+        ++cnt.shadow;
+        c = add(c, scl(mul(f_d, rad), lw));
+        c = add(c, scl(mul(f_s, rad), lw));
+    }
+    return c;
+}
+
 // Lanes take vertices in queue order.  A vertex without a record (nothing to add but the ambient term) is finished on the
 // spot; the others are collected per wave and evaluated 64 at a time, so that the lanes of the expensive part are all busy
 // however the lit and the shadowed vertices are mixed.
@@ -1165,6 +1219,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const bool on = lane < n_ready;
         const unsigned vl = mine[on ? lane : 0u];
         const unsigned v = shard_base + vl;
+        if (defer == 3) {
+            const float4 fk = B.n_key[v], fd2 = B.view_mat[v], ws = B.kd_slot[v], dt = W.shadow[gen & 1].d_time[shadow_base + vl];
+            const V c = gather_lean(S, on, mk(fk.x, fk.y, fk.z), mk(fd2.x, fd2.y, fd2.z), mk(dt.x, dt.y, dt.z), fd2.w, __float_as_uint(fk.w), cnt);
+            if (on) finish(c, ws, __float_as_int(ws.w));
+            return;
+        }
         const float4 af = defer == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : B.amb_first[v], w = B.weight[v];
         const unsigned long long have = (unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w);
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
