@@ -1194,6 +1194,8 @@ __device__ __forceinline__ V gather_lean(const DevScene &S, bool lit, V f_d, V f
 // spot; the others are collected per wave and evaluated 64 at a time, so that the lanes of the expensive part are all busy
 // however the lit and the shadowed vertices are mixed.
 constexpr int GATHER_QUEUE = 128;
+// LEAN: gather mode 3 as a kernel of its own (what it leaves out is most of the code, and the registers that code would claim).
+template <bool LEAN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES))) light_gather_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of, int k_total,
                                                             int k_pad, int slot_table, int has_records, int defer,
                                                             unsigned long long *__restrict__ stats) {
@@ -1219,13 +1221,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const bool on = lane < n_ready;
         const unsigned vl = mine[on ? lane : 0u];
         const unsigned v = shard_base + vl;
-        if (defer == 3) {
+        if (LEAN) {
             const float4 fk = B.n_key[v], fd2 = B.view_mat[v], ws = B.kd_slot[v], dt = W.shadow[gen & 1].d_time[shadow_base + vl];
             const V c = gather_lean(S, on, mk(fk.x, fk.y, fk.z), mk(fd2.x, fd2.y, fd2.z), mk(dt.x, dt.y, dt.z), fd2.w, __float_as_uint(fk.w), cnt);
             if (on) finish(c, ws, __float_as_int(ws.w));
             return;
         }
-        const float4 af = defer == 3 ? make_float4(0.f, 0.f, 0.f, 0.f) : B.amb_first[v], w = B.weight[v];
+        const float4 af = B.amb_first[v], w = B.weight[v];
         const unsigned long long have = (unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w);
         V c = pass == 0 ? mk(af.x, af.y, af.z) : mk(0, 0, 0);
         c = gather_vertex(S, W, gen, v, vl, shadow_base, light_of, k_total, k0, kn, k_pad, slot_table, defer, on, on ? have : 0ull, c, cnt);
@@ -1238,7 +1240,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_GAT
         const unsigned v = shard_base + (valid ? vl : vbase);
         // defer 3: as 2, and the vertices have neither an ambient term nor a light-sample record: one the emitter's ray does
         // not reach adds exactly nothing (its sum is throughput x 0), so all that is read of it is the ray's outcome
-        const bool lean = defer == 3;
+        constexpr bool lean = LEAN;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 af = lean ? zero4 : B.amb_first[v], w = lean ? zero4 : B.weight[v];
         unsigned long long have = has_records && !lean ? ((unsigned long long)(kn > 32 ? __float_as_uint(w.w) : 0u) << 32 | __float_as_uint(af.w)) : 0ull;
@@ -2400,9 +2402,9 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
             auto launch_gather = [&](hipStream_t on, int gen) {
                 LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, on);
                 if (emitter_rays)
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
+                    hipLaunchKernelGGL(pt ? light_gather_kernel<true> : light_gather_kernel<false>, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
                 else
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[0] ? 1 : 0, s->stats);
+                    hipLaunchKernelGGL(light_gather_kernel<false>, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[0] ? 1 : 0, s->stats);
             };
             for (int gen = 0; gen < n_gen; ++gen) {
                 launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
@@ -2438,7 +2440,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 if (emitter_rays) {   // the rays are there already: trace them, then evaluate the emitter where they arrived
                     launch_trace(s, lighting, true, grid, gen, 1);
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
+                    hipLaunchKernelGGL(pt ? light_gather_kernel<true> : light_gather_kernel<false>, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, pt ? 3 : 2, s->stats);
                 }
                 for (int pass = 0; pass < n_pass && !emitter_rays; ++pass) {
                     if (pass > 0)
@@ -2450,11 +2452,11 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                     }
                     launch_trace(s, lighting, true, grid, gen, 0);
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
+                    hipLaunchKernelGGL(light_gather_kernel<false>, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[(size_t)pass] ? 1 : 0, s->stats);
                 }
                 if (n_pass == 0 && !pt) {   // ambient only
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
-                    hipLaunchKernelGGL(light_gather_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, -1, 0, 0, s->stats);
+                    hipLaunchKernelGGL(light_gather_kernel<false>, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, 0, s->light_of, 0, 1, -1, 0, 0, s->stats);
                 }
                 HIP_OK(hipEventRecord(s->lit[gen], lighting));
             }
