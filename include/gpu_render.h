@@ -296,6 +296,10 @@ uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples);
 int32_t rt_scene_shadow_order_free(const rt_scene *scene);
 /* The same decision from a scene description alone (host only, no GPU needed; RT_ANY_ORDERED is not consulted). */
 int32_t rt_shadow_order_free(const rt_scene_desc *desc);
+/* Test hook: 1 when the scene is shaded by the build of the shading kernel that holds only what a scene of regular
+ * materials without textures runs of calculate_color, trace_rec and path_trace (src/ray_trace.cpp:154-447, 646-869, 871-1139):
+ * no texture lookups, no mirror, conductor or dielectric branch.  RT_PLAIN_SHADING=0 at rt_scene_create: never. */
+int32_t rt_scene_plain_shading(const rt_scene *scene);
 
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders

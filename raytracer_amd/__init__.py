@@ -184,6 +184,12 @@ class Renderer:
         self._g.rt_scene_shadow_order_free.argtypes = [C.c_void_p]
         return bool(self._g.rt_scene_shadow_order_free(self._ptr))
 
+    def plain_shading(self):
+        """True when the scene is shaded by the shading kernel built without textures and mirrors (rt_scene_plain_shading)."""
+        self._g.rt_scene_plain_shading.restype = C.c_int32
+        self._g.rt_scene_plain_shading.argtypes = [C.c_void_p]
+        return bool(self._g.rt_scene_plain_shading(self._ptr))
+
     def set_counters(self, enabled):
         self._check(self._g.rt_set_counters(self._ptr, 1 if enabled else 0), "rt_set_counters")
 

@@ -545,7 +545,9 @@ __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard,
 
 // ---- shade: the hit-side half of trace_rec (src/ray_trace.cpp:646-869) / path_trace (:871-1139) ------------------
 // Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
-template <bool PT>
+// PLAIN: the scene has no textures and no mirror, conductor or dielectric material, so the code for them is left out
+// (the same statements otherwise; what remains needs fewer registers and less room in the instruction cache).
+template <bool PT, bool PLAIN>
 // waves per SIMD the register allocation aims at, measured (4K / 64 spp frame): shade 3: 86 ms, 4: 81, 5: 106 (spills);
 // gather (two emitter samples per round, packed) 4: 58.5 ms, 5: 61.8, 6: 64.5, 8: 67.7
 #ifndef RT_SHADE_WAVES
@@ -627,14 +629,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                 V p = add(o, scl(d, h.t));
                 V normal = normal_of(S, sf, p);
                 const float helper_x = sf.kind == 2 ? S.planes[sf.index].raw_normal_x : normal.x;
-                apply_normal_map(S, sf, p, normal, c);
-                apply_bump_map(S, sf, p, normal, c);
+                if (!PLAIN) {
+                    apply_normal_map(S, sf, p, normal, c);
+                    apply_bump_map(S, sf, p, normal, c);
+                }
                 const float seps = S.seps;
                 const int child_df = (depth + 1) | ((int)culling << 16);
                 if (!PT) {
                     // ---- trace_rec ---------------------------------------------------------------------
                     V shade_p = p, shade_n = normal;
-                    if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
+                    if (PLAIN) {
+                    } else if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
                         V R = reflect_dir(normal, d, m.roughness, key);
                         V coef = mk(m.mirror);
                         if (m.type == RT_MAT_CONDUCTOR) {
@@ -688,9 +693,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                         }
                     }
                     // own colour: calculate_color(include_ambient = true) at (shade_p, shade_n)
-                    V kd, ks, kd_rr, rep;
-                    bool replace_all;
-                    resolve_textures(S, sf, shade_p, m, kd, ks, kd_rr, replace_all, rep, c);
+                    V kd = mk(m.diffuse), ks = mk(m.specular), kd_rr = kd, rep = mk(0, 0, 0);
+                    bool replace_all = false;
+                    if (!PLAIN) resolve_textures(S, sf, shade_p, m, kd, ks, kd_rr, replace_all, rep, c);
                     if (replace_all) {
                         accum_add(W, slot, mul(thr, rep));
                     } else {
@@ -707,17 +712,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
                     }
                 } else {
                     // ---- path_trace ------------------------------------------------------------------------
-                    V kd, ks, kd_rr, rep;
-                    bool replace_all;
+                    V kd = mk(m.diffuse), ks = mk(m.specular), kd_rr = kd, rep = mk(0, 0, 0);
+                    bool replace_all = false;
                     const uint32_t texels_before = c.texels;
-                    resolve_textures(S, sf, p, m, kd, ks, kd_rr, replace_all, rep, c);
+                    if (!PLAIN) resolve_textures(S, sf, p, m, kd, ks, kd_rr, replace_all, rep, c);
                     const uint32_t texels_resolve = c.texels - texels_before;
                     if (replace_all) {
                         accum_add(W, slot, mul(thr, rep));
                     } else {
                         V emission = sf.kind == 0 ? mk(S.instances[sf.instance].emission)
                                                   : (sf.kind == 1 ? mk(S.spheres[sf.index].emission) : mk(0, 0, 0));
-                        if (m.type != RT_MAT_REGULAR) {
+                        if (!PLAIN && m.type != RT_MAT_REGULAR) {
                             if (!((float)depth < S.max_depth)) {
                                 accum_add(W, slot, mul(thr, emission));   // specular surface at the depth limit keeps its emission only
                             } else if (m.type == RT_MAT_MIRROR || m.type == RT_MAT_CONDUCTOR) {
@@ -868,7 +873,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHA
             const unsigned ci = wave_append(want, next_count);
             if (!want) continue;
             ++c.secondary;
-            if (!diffuse) {
+            if (!PLAIN && !diffuse) {
                 put_path(W, gen + 1, shard, ci, c_o[r], c_d[r], time, c_thr[r], c_key[r], slot, c_df[r]);
             } else {
                 const bool cosine = cam.importance_sampling != 0;
@@ -1403,6 +1408,7 @@ struct rt_scene {
     std::vector<char> pass_has_emitter;   // per pass of 64 light samples: does it hold samples of a sphere emitter
     bool has_dielectric = false;
     bool only_regular_materials = true;   // no mirror, conductor or dielectric: recursive ray tracing (trace_rec) never spawns a ray
+    bool plain_shading = false;           // and no texture either: the shading kernel without the code for them (RT_PLAIN_SHADING=0: the full kernel)
     bool single_sphere_emitter = false;   // the scene's lights are exactly one sphere emitter
     // this rank's tiles of a frame that is split over several ranks (see shard_owner)
     int *owned_tiles = nullptr;       // device copy of the list
@@ -2118,6 +2124,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             s->only_regular_materials &= d->materials[i].type == RT_MAT_REGULAR;
         }
         s->single_sphere_emitter = d->n_lights == 1 && d->lights[0].type == RT_LIGHT_SPHERE && d->lights[0].samples <= 64;
+        s->plain_shading = s->only_regular_materials && d->n_textures == 0 && !(getenv("RT_PLAIN_SHADING") && atoi(getenv("RT_PLAIN_SHADING")) == 0);
         s->shadow_order_free = !(getenv("RT_ANY_ORDERED") && atoi(getenv("RT_ANY_ORDERED")) != 0) && shadow_answers_order_free(d);
     }
     *out = s;
@@ -2417,10 +2424,9 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 if (gen >= 2) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen - 2], 0));
                 {
                     LaunchTimer timer(s, RT_KERNEL_SHADE, s->stream);
-                    if (pt)
-                        hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
-                    else
-                        hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
+                    typedef void (*ShadeFn)(DevScene, rt_camera_desc, Batch, Wavefront, int, int, unsigned long long *);
+                    const ShadeFn fn = s->plain_shading ? (pt ? shade_kernel<true, true> : shade_kernel<false, true>) : (pt ? shade_kernel<true, false> : shade_kernel<false, false>);
+                    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
                 }
                 const int n_pass = n_pass_all;
                 if (pair_gather) {   // rays and any-hit trace in turn; the gather follows the next closest-hit trace (the last one: at once)
@@ -2608,6 +2614,7 @@ int rt_render(rt_scene *s, const rt_camera_desc *cam, float *hdr_out, rt_stats *
 int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample) { return queue_shard_of(group_of_sample, sample); }
 uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { return max_shard_groups(groups_per_sample, samples); }
 int32_t rt_scene_shadow_order_free(const rt_scene *s) { return s && s->shadow_order_free ? 1 : 0; }
+int32_t rt_scene_plain_shading(const rt_scene *s) { return s && s->plain_shading ? 1 : 0; }
 int32_t rt_shadow_order_free(const rt_scene_desc *d) { return d && d->abi_version == RT_ABI_VERSION && shadow_answers_order_free(d) ? 1 : 0; }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major

@@ -99,3 +99,36 @@ def test_gather_beside_shading_changes_nothing(name, scene_dir, repo_root, monke
     ref, _ = Oracle(sc).render(cam)
     err = rel_err(img1, ref).max(axis=2)
     assert (err > 2e-4).mean() <= 2e-3
+
+
+@pytest.mark.parametrize("name", ["brdfs", "pt_uniform", "pt_env", "emitters", "one_sphere_emitter", "mesh70k"])
+def test_shading_kernel_without_textures_and_mirrors_is_the_same_shading(name, scene_dir, repo_root, monkeypatch):
+    """A scene with regular materials only and no texture is shaded by a build of the shading kernel that leaves the code
+    for the other materials and for textures out (RT_PLAIN_SHADING=0 at scene creation: the full kernel).  The
+    statements that remain are the same, no path splits in such a scene, and so the image is the same bit for bit."""
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    monkeypatch.setenv("RT_PAIR_GATHER", "0")     # (beside the gather, a sample's additions come in arrival order)
+    if name == "one_sphere_emitter":
+        path = scenegen.write_path_traced_scene(scene_dir + "/pt_small", n=48, width=96, height=54, spp=16)
+    elif name == "mesh70k":
+        path = scenegen.write_mesh_scene(scene_dir + "/mesh")
+    else:
+        path = scene_path(name, scene_dir, repo_root)
+    sc = R.Scene(path)
+    cam = sc.camera(0)
+    plain = R.Renderer(sc)
+    monkeypatch.setenv("RT_PLAIN_SHADING", "0")
+    full = R.Renderer(sc)
+    if not plain.plain_shading():
+        pytest.skip("this scene has a texture or a material that is not regular")
+    assert not full.plain_shading()
+    img_p, st_p = plain.render(cam)
+    img_f, st_f = full.render(cam)
+    assert np.array_equal(img_p.view(np.uint32), img_f.view(np.uint32))
+    assert (st_p.primary_rays, st_p.secondary_rays, st_p.shadow_rays, st_p.shadow_rays_traced) == (
+        st_f.primary_rays, st_f.secondary_rays, st_f.shadow_rays, st_f.shadow_rays_traced)
+    plain.set_counters(True)                      # the counted render uses the same kernel: its counts are the oracle's
+    _, st_c = plain.render(cam)
+    ref, st_o = Oracle(sc).render(cam)
+    assert (st_c.primary_rays, st_c.secondary_rays, st_c.shadow_rays, st_c.nodes_visited, st_c.triangle_tests, st_c.shaded_hits) == (
+        st_o.primary_rays, st_o.secondary_rays, st_o.shadow_rays, st_o.nodes_visited, st_o.triangle_tests, st_o.shaded_hits)
