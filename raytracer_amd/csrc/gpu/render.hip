@@ -547,16 +547,20 @@ __device__ __forceinline__ void put_path(const Wavefront &W, int gen, int shard,
 // Everything except the light loop of calculate_color, which becomes a vertex record for the direct kernel.
 // PLAIN: the scene has no textures and no mirror, conductor or dielectric material, so the code for them is left out
 // (the same statements otherwise; what remains needs fewer registers and less room in the instruction cache).
-template <bool PT, bool PLAIN>
-// waves per SIMD the register allocation aims at, measured (4K / 64 spp frame): shade 3: 86 ms, 4: 81, 5: 106 (spills);
-// gather (two emitter samples per round, packed) 4: 58.5 ms, 5: 61.8, 6: 64.5, 8: 67.7
+// waves per SIMD the register allocation aims at, measured (4K / 64 spp frame).  The full shading kernel 3: 86 ms, 4: 81,
+// 5: 106 (spills); the plain one, by the frame's time, 3: 419 ms, 4: 417, 5: 413, 6: 420.  Gather (two emitter samples per
+// round, packed) 4: 58.5 ms, 5: 61.8, 6: 64.5, 8: 67.7
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
+#endif
+#ifndef RT_PLAIN_SHADE_WAVES
+#define RT_PLAIN_SHADE_WAVES 5
 #endif
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, int emitter_rays, unsigned long long *__restrict__ stats) {
+template <bool PT, bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? RT_PLAIN_SHADE_WAVES : RT_SHADE_WAVES))) shade_kernel(DevScene S, rt_camera_desc cam, Batch b, Wavefront W, int gen, int emitter_rays, unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
     const unsigned shard_base = shard * W.shard_entries;
     unsigned count = *counter_of(W, Q_PATH, gen, shard);
