@@ -28,7 +28,7 @@ raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 raytracer: raytracer_amd/csrc/host/main.cpp raytracer_amd/librt_host.so raytracer_amd/librt_gpu.so
 	$(CXX) -std=c++17 -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Iraytracer_amd/csrc/host $< -L/opt/rocm/lib -lamdhip64 -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@
 
-oracle:
+oracle: raytracer_amd/librt_gpu.so
 	$(MAKE) -C oracle all
 
 clean:

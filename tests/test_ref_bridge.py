@@ -1,0 +1,162 @@
+"""The reference-side binding (oracle/ref_bridge.cpp: the reference's own parser, shapes, lights and BVH flattened into an
+rt_scene_desc, compiled against the reference where it lies) against this repository's host ingest of the same file.
+
+CPU: every array of the two descriptors, field by field -- integers and everything copied from the scene file equal,
+derived floats (inverse matrices, normalised vectors; the reference is built with -ffast-math) to 1e-5.  Instances are
+matched through the tree's leaf entries, since their order in the array is the binding's own business.
+GPU: the frame rendered from the reference's data structures through the C ABI against the frame rendered from the host
+ingest: the same image.  The binary is built where the reference is present and travels with the tree; without it the
+tests skip."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import raytracer_amd as R
+from raytracer_amd import _abi as A
+from raytracer_amd import scenegen
+from golden import scenes as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BRIDGE = os.path.join(ROOT, "oracle", "_ref", "ref_bridge")
+needs_bridge = pytest.mark.skipif(not os.path.exists(BRIDGE), reason="oracle/_ref/ref_bridge is built only where the reference is present")
+
+SCENES = ["simple", "mesh70k"] + sorted(S.SCENES)
+
+
+def scene_path(name, scene_dir):
+    if name == "simple":
+        return os.path.join(ROOT, "scenes", "simple.json")
+    if name == "mesh70k":
+        return scenegen.write_mesh_scene(scene_dir, name="mesh70k", n=188, width=320, height=180)
+    return S.SCENES[name][0](scene_dir)
+
+
+def records(ptr, n, struct):
+    """An array of C structs as a numpy structured array (one field per struct member)."""
+    dt = np.dtype([(f, np.float32 if t in (A.f32,) else np.int32) if not hasattr(t, "_length_") else (f, np.float32, (t._length_,))
+                   for f, t in struct._fields_])
+    assert dt.itemsize == C.sizeof(struct)
+    if n == 0:
+        return np.zeros(0, dt)
+    return np.frombuffer(C.string_at(ptr, n * C.sizeof(struct)), dtype=dt).copy()
+
+
+def dumped(prefix, name, struct):
+    dt = records(None, 0, struct).dtype
+    return np.fromfile(f"{prefix}.{name}.bin", dtype=dt)
+
+
+def same(a, b, what, float_tol=1e-5):
+    assert len(a) == len(b), f"{what}: {len(a)} records against {len(b)}"
+    for f in a.dtype.names:
+        x, y = a[f], b[f]
+        if x.dtype == np.int32:
+            assert np.array_equal(x, y), f"{what}.{f}"
+        else:
+            scale = np.maximum(1.0, np.maximum(np.abs(x), np.abs(y)))
+            assert np.all(np.abs(x - y) <= float_tol * scale), f"{what}.{f}: max difference {np.abs(x - y).max()}"
+
+
+def run_bridge(path, prefix, mode):
+    subprocess.run([BRIDGE, path, prefix, mode], check=True, cwd=os.path.dirname(path), timeout=600)
+
+
+@needs_bridge
+@pytest.mark.parametrize("name", SCENES)
+def test_descriptor_from_the_reference_equals_the_host_ingest(name, scene_dir, tmp_path):
+    path = scene_path(name, scene_dir)
+    prefix = str(tmp_path / "b")
+    run_bridge(path, prefix, "dump")
+    sc = R.Scene(path)
+    d = sc.desc
+    same(dumped(prefix, "triangles", A.Triangle), records(d.triangles, d.n_triangles, A.Triangle), "triangles")
+    same(dumped(prefix, "spheres", A.Sphere), records(d.spheres, d.n_spheres, A.Sphere), "spheres")
+    same(dumped(prefix, "planes", A.Plane), records(d.planes, d.n_planes, A.Plane), "planes")
+    same(dumped(prefix, "materials", A.Material), records(d.materials, d.n_materials, A.Material), "materials")
+    same(dumped(prefix, "images", A.Image), records(d.images, d.n_images, A.Image), "images")
+    bt, ht = dumped(prefix, "textures", A.Texture), records(d.textures, d.n_textures, A.Texture)
+    for t in (bt, ht):   # the background texture made for an environment map is an image and a mode, nothing else is read
+        made = t["decal_mode"] == 3
+        for f in ("bump_factor", "noise_scale", "num_octaves"):
+            t[f][made] = 0
+        t["noise_conversion"][made] = 0
+    same(bt, ht, "textures")
+    same(dumped(prefix, "lights", A.Light), records(d.lights, d.n_lights, A.Light), "lights")
+    assert np.array_equal(np.fromfile(prefix + ".texels_u8.bin", np.uint8), np.frombuffer(C.string_at(d.texels_u8, d.n_texels_u8), np.uint8))
+    assert np.array_equal(np.fromfile(prefix + ".texels_f32.bin", np.uint32),
+                          np.frombuffer(C.string_at(d.texels_f32, d.n_texels_f32 * 4), np.uint32))
+    # The tree: node for node where the host builder reproduces the reference's (it does wherever the boxes agree to the bit:
+    # geometry that is not transformed; the reference's -ffast-math build rounds transformed boxes its own way, and a
+    # different last bit may send a primitive to the other side of a split).  The leaf entries are the same set either way.
+    bn, hn = dumped(prefix, "bvh_nodes", A.BvhNode), records(d.bvh_nodes, d.n_bvh_nodes, A.BvhNode)
+    bp, hp = dumped(prefix, "bvh_prims", A.BvhPrim), records(d.bvh_prims, d.n_bvh_prims, A.BvhPrim)
+    same_tree = len(bn) == len(hn) and all(np.array_equal(bn[f], hn[f]) for f in ("offset", "n_prims", "axis"))
+    if name not in ("transforms",):
+        assert same_tree, "the host builder's tree is not the reference's"
+    if same_tree:
+        same(bn, hn, "bvh_nodes")
+        assert np.array_equal(bp["shape"], hp["shape"])
+    bi, hi = dumped(prefix, "instances", A.Instance), records(d.instances, d.n_instances, A.Instance)
+    assert len(bi) == len(hi) and len(bp) == len(hp)
+    brefs = np.fromfile(prefix + ".texture_refs.bin", np.int32)
+    hrefs = np.frombuffer(C.string_at(d.texture_refs, d.n_texture_refs * 4), np.int32) if d.n_texture_refs else np.zeros(0, np.int32)
+
+    def placements(prims, insts):   # (shape, the reference's id of the placement) -> instance record; spheres have none
+        out = {}
+        for shape, inst in zip(prims["shape"], prims["instance"]):
+            key = (int(shape), int(insts[inst]["ref_id"]) if inst >= 0 else -1)
+            assert key not in out, "a leaf entry twice"
+            out[key] = int(inst)
+        return out
+    pb, ph = placements(bp, bi), placements(hp, hi)
+    assert pb.keys() == ph.keys(), "the leaf entries are not the same set"
+    pairs = np.array(sorted({(pb[k], ph[k]) for k in pb if pb[k] >= 0}), dtype=np.int64).reshape(-1, 2)
+    assert len(pairs) == len(np.unique(pairs[:, 0])) == len(np.unique(pairs[:, 1])), "the two instance numberings do not map one to one"
+    a, b = bi[pairs[:, 0]], hi[pairs[:, 1]]
+    for rec_a, rec_b in zip(a, b):
+        assert list(brefs[rec_a["tex_offset"]:rec_a["tex_offset"] + rec_a["tex_count"]]) == \
+               list(hrefs[rec_b["tex_offset"]:rec_b["tex_offset"] + rec_b["tex_count"]])
+    a, b = a.copy(), b.copy()
+    a["tex_offset"] = b["tex_offset"] = 0
+    same(a, b, "instances")
+
+    def texture_lists(recs, refs):
+        return [list(refs[r["tex_offset"]:r["tex_offset"] + r["tex_count"]]) for r in recs]
+    assert texture_lists(dumped(prefix, "spheres", A.Sphere), brefs) == texture_lists(records(d.spheres, d.n_spheres, A.Sphere), hrefs)
+    assert texture_lists(dumped(prefix, "planes", A.Plane), brefs) == texture_lists(records(d.planes, d.n_planes, A.Plane), hrefs)
+    # camera and the scene's scalars
+    cam = sc.camera(0)
+    bc = np.fromfile(prefix + ".camera.bin", np.uint8)
+    hc = np.frombuffer(C.string_at(C.byref(cam), C.sizeof(A.CameraDesc)), np.uint8)
+    fl = C.sizeof(A.CameraDesc) // 4
+    bcf, hcf = bc.view(np.float32)[:fl], hc.view(np.float32)[:fl]
+    bci, hci = bc.view(np.int32)[:fl], hc.view(np.int32)[:fl]
+    assert np.all((bci == hci) | (np.abs(bcf - hcf) <= 1e-5 * np.maximum(1.0, np.abs(hcf)))), "camera"
+    s = np.fromfile(prefix + ".scalars.bin", np.float32)
+    want = [d.intersection_epsilon, d.shadow_ray_epsilon, d.max_depth, *d.ambient_light, *d.background_color, d.background_texture, d.is_probe]
+    assert np.allclose(s[:11], np.array(want, np.float32), rtol=1e-6, atol=0)
+
+
+@needs_bridge
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple", "materials", "transforms", "textures", "brdfs", "background", "mesh70k"])
+def test_frame_from_the_reference_data_structures(name, scene_dir, tmp_path):
+    """rt_scene_create + rt_render fed by the reference's parser and BVH builder: the image of the host ingest's scene.
+    The two descriptors differ in last bits (the reference's -ffast-math build inverts and normalises its own way: the
+    inverse of the identity has 0.99999994 on its diagonal), so the images are compared to 1e-3 on 99.9 % of the values.
+    Scenes lit by emitter triangles are left out: a shadow ray towards a sample on an emitter starts one shadow-ray
+    epsilon off the surface and meets the emitter at `distance - epsilon` to rounding, which the reference's test
+    `t < distance - epsilon` (src/ray_trace.cpp:232-241) then decides sample by sample -- one last bit in the camera moves
+    a third of such a frame's pixels by a per cent or more (the CPU checker and the GPU agree on every such frame)."""
+    path = scene_path(name, scene_dir)
+    prefix = str(tmp_path / "b")
+    run_bridge(path, prefix, "render")
+    sc = R.Scene(path)
+    cam = sc.camera(0)
+    img, _ = R.Renderer(sc).render(cam)
+    got = np.fromfile(prefix + ".hdr.bin", np.float32).reshape(img.shape)
+    err = np.abs(got - img) / np.maximum(np.abs(img), 1.0 / 255.0)
+    assert (err > 1e-3).mean() <= 1e-3, f"{(err > 1e-3).sum()} values differ; max {err.max()}"
