@@ -926,7 +926,18 @@ __device__ __forceinline__ unsigned record_slot(const int *__restrict__ light_of
     return slot_table >= 0 ? (unsigned)light_of[slot_table + (int)k] : (unsigned)kl;
 }
 
-__global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
+// SPHERES: the pass holds samples of a sphere emitter.  A pass without any is set up by a build that leaves that code and the
+// registers it keeps across an emitter's samples out.  Waves per SIMD the register allocation aims at, measured on the
+// textured 1080p / 64 spp frame (two area lights of 16 samples): 3 (139 registers, the compiler's own choice): 78.4 ms,
+// 4: 66.4, 5: 88.7 (spills), 6: 145; the build without sphere emitters 3: 69.0, 4: 63.0, 5: 58.5, 6: 59.3.
+#ifndef RT_SETUP_WAVES
+#define RT_SETUP_WAVES 4
+#endif
+#ifndef RT_SETUP_WAVES_NO_SPHERES
+#define RT_SETUP_WAVES_NO_SPHERES 5
+#endif
+template <bool SPHERES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPHERES ? RT_SETUP_WAVES : RT_SETUP_WAVES_NO_SPHERES))) light_setup_kernel(DevScene S, Wavefront W, int gen, int pass, const int *__restrict__ light_of,
                                                            int k_total, int k_pad, int slot_table, int share_rays,
                                                            unsigned long long *__restrict__ stats) {
     const int shard = blockIdx.x % N_SHARDS;
@@ -971,7 +982,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
             V rad, ldir, fd = mk(0, 0, 0), fs = mk(0, 0, 0);
             float dist;
             bool want;
-            if (share_rays != 0 && L.type == RT_LIGHT_SPHERE) {
+            if (SPHERES && share_rays != 0 && L.type == RT_LIGHT_SPHERE) {
                 // Deferred: only the light's one shadow ray per vertex is set up here, at the light's first sample of the
                 // pass; the samples themselves are evaluated by light_gather for the vertices the ray reaches.
                 if (li != kept_light) {   // (uniform over the wave)
@@ -1003,7 +1014,7 @@ __global__ void __launch_bounds__(256) light_setup_kernel(DevScene S, Wavefront 
                 key = __float_as_uint(nk.w);
             }
             const float r1 = rnd(key, DIM_LIGHT + 2 * k), r2 = rnd(key, DIM_LIGHT + 2 * k + 1);
-            if (L.type == RT_LIGHT_SPHERE) {
+            if (SPHERES && L.type == RT_LIGHT_SPHERE) {
                 const rt_sphere &sph = S.spheres[L.sphere];
                 if (li != kept_light) {
                     kept_light = li;
@@ -2433,10 +2444,14 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, s->stream, s->dev, *cam, b, W, gen, emitter_rays, s->stats);
                 }
                 const int n_pass = n_pass_all;
+                typedef void (*SetupFn)(DevScene, Wavefront, int, int, const int *, int, int, int, int, unsigned long long *);
+                auto setup_fn = [&](int pass) -> SetupFn {   // a pass without sphere-emitter samples: the build without their code
+                    return (size_t)pass < s->pass_has_emitter.size() && s->pass_has_emitter[(size_t)pass] ? light_setup_kernel<true> : light_setup_kernel<false>;
+                };
                 if (pair_gather) {   // rays and any-hit trace in turn; the gather follows the next closest-hit trace (the last one: at once)
                     if (!emitter_rays) {
                         LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, s->stream);
-                        hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
+                        hipLaunchKernelGGL(setup_fn(0), dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
                     }
                     launch_trace(s, s->stream, true, grid, gen, emitter_rays ? 1 : 0);
                     if (gen == n_gen - 1) {
@@ -2458,7 +2473,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                                               N_SHARDS * COUNTER_STRIDE * sizeof(unsigned), lighting));
                     {
                         LaunchTimer timer(s, RT_KERNEL_LIGHT_SETUP, lighting);
-                        hipLaunchKernelGGL(light_setup_kernel, dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
+                        hipLaunchKernelGGL(setup_fn(pass), dim3(grid), dim3(256), 0, lighting, s->dev, W, gen, pass, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
                     }
                     launch_trace(s, lighting, true, grid, gen, 0);
                     LaunchTimer timer(s, RT_KERNEL_LIGHT_GATHER, lighting);
