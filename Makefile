@@ -22,8 +22,9 @@ build/bvh_gpu.o: raytracer_amd/csrc/gpu/bvh_gpu.hip raytracer_amd/csrc/gpu/rt_bv
 raytracer_amd/librt_gpu.so: build/render.o build/bvh_gpu.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
+# (the scene cache keys its files by a hash of the host sources: a cache written by another ingest or tree builder is not used)
 raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
-	$(CXX) -std=c++17 -O2 -fPIC -shared -Wall -Iinclude -Iraytracer_amd/csrc/host $(HOST_SRCS) -lz -o $@
+	$(CXX) -std=c++17 -O2 -fPIC -shared -Wall -Iinclude -Iraytracer_amd/csrc/host -DRT_HOST_SOURCE_STAMP=\"$$(cat $(HOST_SRCS) $(HOST_HDRS) | sha256sum | cut -c1-32)\" $(HOST_SRCS) -lz -pthread -o $@
 
 raytracer: raytracer_amd/csrc/host/main.cpp raytracer_amd/librt_host.so raytracer_amd/librt_gpu.so
 	$(CXX) -std=c++17 -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Iraytracer_amd/csrc/host $< -L/opt/rocm/lib -lamdhip64 -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@

@@ -67,7 +67,11 @@ typedef struct rt_instance {
     int32_t tex_offset;    /* range in texture_refs */
     int32_t tex_count;
     int32_t ref_id;        /* the reference's instance id: mesh _id, MeshInstance _id, or 123456 */
-    int32_t identity;      /* 1 when model is exactly the identity (inverse transform is a no-op) */
+    int32_t identity;      /* 1 when model is exactly the identity.  inv_model is then k I, with k what the caller's inverse makes
+                            * of 1 / 1 (the reference's: 1 - 2^-24, src/algebra.cpp:345-347), and a triangle test multiplies the
+                            * ray's origin and direction by k in place of the matrix product (the same values, src/shapes.cpp:224-230).
+                            * One k per scene: the first such placement's inv_model[0]; placements whose inverse is another
+                            * matrix take the general way. */
 } rt_instance;
 
 /* triangle in OBJECT space (src/shapes.h:110-149).  The reference intersects in object space with

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) records_kernel(const float *__restrict__ 
 // the scene: scaled vertex and edges as the reference computes them, src/shapes.cpp:22-33,236-237; the face normal).
 __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restrict__ in, const float *__restrict__ bounds, const unsigned *__restrict__ order, int n,
                                                        const rt_triangle *__restrict__ triangles, int n_triangles, const rt_instance *__restrict__ instances,
-                                                       float4 *__restrict__ prims, int4 *__restrict__ prim_meta) {
+                                                       float id_scale, float4 *__restrict__ prims, int4 *__restrict__ prim_meta) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const unsigned src = order[j];
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restr
             e2[a] = t.c3[a] * 1000.0f - c1s[a];
         }
         const rt_instance &in_ = instances[p.instance];
-        const bool plain = in_.identity && in_.motionblur[0] == 0.f && in_.motionblur[1] == 0.f && in_.motionblur[2] == 0.f;
+        const bool plain = plain_placement(in_, id_scale);
         word = p.instance | (plain ? 0 : PRIM_XFORM_BIT);
         e[0] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
         e[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restr
 }  // namespace
 
 int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, const rt_triangle *d_triangles, int n_triangles, const rt_instance *d_instances,
-                        int max_depth, DeviceBvh &out, std::string &err) {
+                        float id_scale, int max_depth, DeviceBvh &out, std::string &err) {
     out = DeviceBvh();
     if (n <= 0) return 0;
     // box of the scene and of the primitives' centres (one pass on the host, while the arrays are at hand)
@@ -264,7 +264,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         }
         BVH_HIP_OK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys, order_in, order, n, 0, 63, 0));
     }
-    hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, d_prims, d_meta);
+    hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, d_prims, d_meta);
     BVH_HIP_OK(hipGetLastError());
     if (n == 1) {   // the root is the one leaf
         out.root_ref = (int)0x80000000u;

@@ -1923,6 +1923,13 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         }
         if (d->n_bvh_nodes > 0) root_ref = ref_of(0);
     }
+    // the inverse of the identity as this scene's inverse routine makes it (see plain_placement): the first such placement's
+    float id_scale = 1.0f;
+    for (int i = 0; i < d->n_instances; ++i)
+        if (d->instances[i].identity) {
+            id_scale = d->instances[i].inv_model[0];
+            break;
+        }
     // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
     const int n_host_entries = build_tree ? 0 : d->n_bvh_prims;   // (a tree built on the device makes its entries there)
     std::vector<float4> prims((size_t)n_host_entries * PRIM_STRIDE);
@@ -1945,7 +1952,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             prims[PRIM_STRIDE * i] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
             prims[PRIM_STRIDE * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
             const rt_instance &in = d->instances[p.instance];
-            const bool plain = in.identity && in.motionblur[0] == 0.f && in.motionblur[1] == 0.f && in.motionblur[2] == 0.f;
+            const bool plain = plain_placement(in, id_scale);
             prim_meta[2 * (size_t)i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, t.smooth ? 1 : 0);
             prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), 0.f, 0.f);
         } else {
@@ -1973,7 +1980,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     std::vector<float4> inst((size_t)d->n_instances * 4);
     for (int i = 0; i < d->n_instances; ++i) {
         const rt_instance &in = d->instances[i];
-        int flags = (in.identity ? 1 : 0) | ((in.motionblur[0] != 0.f || in.motionblur[1] != 0.f || in.motionblur[2] != 0.f) ? 2 : 0);
+        int flags = (scaled_identity(in, id_scale) ? 1 : 0) | ((in.motionblur[0] != 0.f || in.motionblur[1] != 0.f || in.motionblur[2] != 0.f) ? 2 : 0);
         for (int r = 0; r < 3; ++r) inst[4 * i + r] = make_float4(in.inv_model[4 * r], in.inv_model[4 * r + 1], in.inv_model[4 * r + 2], in.inv_model[4 * r + 3]);
         inst[4 * i + 3] = make_float4(in.motionblur[0], in.motionblur[1], in.motionblur[2], as_float(flags));
     }
@@ -2020,7 +2027,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     DeviceBvh built;
     if (build_tree) {
         // the walk's stack holds LDS_STACK + SPILL_STACK far children, one per level
-        if (int rc = build_bvh_on_device(d->bvh_prims, d->bvh_prim_bounds, d->n_bvh_prims, D.triangles, d->n_triangles, D.instances, LDS_STACK + SPILL_STACK - 1, built, g_error)) {
+        if (int rc = build_bvh_on_device(d->bvh_prims, d->bvh_prim_bounds, d->n_bvh_prims, D.triangles, d->n_triangles, D.instances, id_scale, LDS_STACK + SPILL_STACK - 1, built, g_error)) {
             rt_scene_destroy(s);
             return rc;
         }
@@ -2076,6 +2083,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         memcpy(D.root_min, d->bvh_nodes[0].bmin, sizeof D.root_min);
         memcpy(D.root_max, d->bvh_nodes[0].bmax, sizeof D.root_max);
     }
+    D.id_scale = id_scale;
     D.ieps = d->intersection_epsilon;
     D.seps = d->shadow_ray_epsilon;
     D.max_depth = d->max_depth;

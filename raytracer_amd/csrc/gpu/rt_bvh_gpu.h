@@ -19,9 +19,9 @@ struct DeviceBvh {
 };
 
 // Builds the tree over `n` (shape, placement) pairs with world-space boxes `bounds` (6 floats each: min, max), both in
-// host memory; triangles and instances are the scene's arrays already on the device.  Returns 0 and the device arrays
+// host memory; triangles and instances are the scene's arrays already on the device; `id_scale`: DevScene::id_scale.  Returns 0 and the device arrays
 // (owned by the caller, hipFree), or an error code with a message.
 int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, const rt_triangle *d_triangles, int n_triangles,
-                        const rt_instance *d_instances, int max_depth, DeviceBvh &out, std::string &err);
+                        const rt_instance *d_instances, float id_scale, int max_depth, DeviceBvh &out, std::string &err);
 
 }  // namespace rt

@@ -62,9 +62,31 @@ struct DevScene {
     int wroot_ref, n_wtop;   // the same for the wide tree
     float root_min[3], root_max[3];
     float ieps, seps, max_depth;
+    float id_scale;   // k of the placements whose inverse is k I (see plain_placement)
     float ambient[3], bg[3];
     int bg_tex, is_probe;
 };
+
+// A placement whose model matrix is the identity has the inverse k I, where k is what the scene's inverse routine makes
+// of 1 / 1: the reference's approximate reciprocal and Newton step give 1 - 2^-24 (src/algebra.cpp:345-347), and the ray
+// its triangle test sees is the world ray times k (src/shapes.cpp:224-230) -- one last bit that decides whether a shadow
+// ray towards a sample on an emitter's triangle ends before or behind distance - epsilon.  Such a placement without
+// motion blur is "plain": its leaf entries carry no transform bit, and the test multiplies by the scene's one k
+// (DevScene::id_scale) instead of reading a matrix.
+__host__ __device__ inline bool plain_placement(const rt_instance &in, float k) {
+    if (!in.identity || in.motionblur[0] != 0.f || in.motionblur[1] != 0.f || in.motionblur[2] != 0.f) return false;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            if (in.inv_model[4 * r + c] != (r == c ? k : 0.f)) return false;
+    return true;
+}
+__host__ __device__ inline bool scaled_identity(const rt_instance &in, float k) {   // the same with motion blur allowed
+    if (!in.identity) return false;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            if (in.inv_model[4 * r + c] != (r == c ? k : 0.f)) return false;
+    return true;
+}
 
 struct Counters {   // per-lane, reduced per wave at kernel end
     uint32_t primary, shadow, secondary, shaded;
@@ -260,17 +282,9 @@ __device__ __forceinline__ void node_step(const DevScene &S, RayState &r, uint2 
 __device__ __forceinline__ float ubyte_f(unsigned v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
 __device__ __forceinline__ f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, f2{b, b}, f2{c, c}); }
 
+// (the step proper, on a record the caller has fetched)
 template <int LEVELS = LDS_STACK>
-__device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, const float4 *top, int n_top) {
-    float4 n0, n1, n2, n3;
-    if (TOP_NODES > 0 && r.cur < n_top) {
-        const float4 *np = top + 4 * r.cur;
-        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        asm volatile("" ::: );   // keeps these LDS reads apart from the global loads below (merged, they become flat loads)
-    } else {
-        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
-        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    }
+__device__ __forceinline__ void wide_step_on(RayState &r, uint2 *lds, uint2 *spill, float4 n0, float4 n1, float4 n2, float4 n3) {
     const unsigned head = __float_as_uint(n0.w);
     const float sx = __uint_as_float(head & 0x7f800000u), sy = n3.z, sz = n3.w;
     const unsigned along = (unsigned)r.sgn & head;
@@ -327,6 +341,20 @@ __device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 
     r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 
+template <int LEVELS = LDS_STACK>
+__device__ __forceinline__ void wide_step(const DevScene &S, RayState &r, uint2 *lds, uint2 *spill, const float4 *top, int n_top) {
+    float4 n0, n1, n2, n3;
+    if (TOP_NODES > 0 && r.cur < n_top) {
+        const float4 *np = top + 4 * r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        asm volatile("" ::: );   // keeps these LDS reads apart from the global loads below (merged, they become flat loads)
+    } else {
+        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    }
+    wide_step_on<LEVELS>(r, lds, spill, n0, n1, n2, n3);
+}
+
 // ---- the any-hit walk of the wide tree -------------------------------------------------------------------------------
 // A ray that only asks whether anything is hit gets the same answer whatever the order of its walk: the answer is "some
 // leaf whose own exact box the ray passes holds an entry the ray hits", and which leaves are reached does not depend on the
@@ -355,16 +383,7 @@ __device__ __forceinline__ bool pop_any_inline(RayState &r, const unsigned *lds)
     return false;
 }
 template <int LEVELS>
-__device__ __forceinline__ void wide_any_step(const DevScene &S, RayState &r, unsigned *lds, unsigned *spill, const float4 *top, int n_top) {
-    float4 n0, n1, n2, n3;
-    if (r.cur < n_top) {
-        const float4 *np = top + 4 * r.cur;
-        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        asm volatile("" ::: );   // (keeps the LDS reads apart from the global loads, see wide_step)
-    } else {
-        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
-        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    }
+__device__ __forceinline__ void wide_any_step_on(RayState &r, unsigned *lds, unsigned *spill, float4 n0, float4 n1, float4 n2, float4 n3) {
     const unsigned head = __float_as_uint(n0.w);
     const float sx = __uint_as_float(head & 0x7f800000u), sy = n3.z, sz = n3.w;
     const bool nx = r.ix < 0, ny = r.iy < 0, nz = r.iz < 0;
@@ -418,6 +437,20 @@ __device__ __forceinline__ void wide_any_step(const DevScene &S, RayState &r, un
     r.cur = h0 ? d0 : (h1 ? d1 : (h2 ? d2 : (h3 ? d3 : REF_POP)));
 }
 
+template <int LEVELS>
+__device__ __forceinline__ void wide_any_step(const DevScene &S, RayState &r, unsigned *lds, unsigned *spill, const float4 *top, int n_top) {
+    float4 n0, n1, n2, n3;
+    if (r.cur < n_top) {
+        const float4 *np = top + 4 * r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        asm volatile("" ::: );   // (keeps the LDS reads apart from the global loads, see wide_step)
+    } else {
+        const float4 *np = S.wnodes + 4 * (size_t)r.cur;
+        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    }
+    wide_any_step_on<LEVELS>(r, lds, spill, n0, n1, n2, n3);
+}
+
 // Pops until an entry whose box still starts before the closest hit; false when the stack is empty.  With
 // CHECK false (an any-hit ray never shortens, so every pushed entry still qualifies) the first entry is taken.
 template <bool CHECK, bool COUNT, int LEVELS = LDS_STACK>
@@ -464,15 +497,19 @@ __device__ __forceinline__ bool prim_test(const DevScene &S, float4 p0, float4 p
     if (inst >= 0) {   // triangle::intersect, src/shapes.cpp:212-279
         if (COUNT) ++c.tri;
         const V ro = mk(r.ox, r.oy, r.oz), rd = mk(r.dx, r.dy, r.dz);
-        V oo = ro, dd = rd;
-        if (inst & PRIM_XFORM_BIT) {
+        V oo, dd;
+        if (!(inst & PRIM_XFORM_BIT)) {   // a plain placement: the inverse is id_scale times the identity
+            oo = scl(ro, S.id_scale);
+            dd = scl(rd, S.id_scale);
+        } else {
             const float4 *ip = S.inst + 4 * (size_t)(inst & PRIM_INDEX_MASK);
             const float4 r3 = ip[3];
             const int flags = __float_as_int(r3.w);
             V moved = ro;
             if (flags & 2) moved = sub(ro, scl(mk(r3.x, r3.y, r3.z), r.time));
             if (flags & 1) {
-                oo = moved;
+                oo = scl(moved, S.id_scale);
+                dd = scl(rd, S.id_scale);
             } else {
                 const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
                 oo = mk((r0.x * moved.x + r0.y * moved.y) + (r0.z * moved.z + r0.w), (r1.x * moved.x + r1.y * moved.y) + (r1.z * moved.z + r1.w),

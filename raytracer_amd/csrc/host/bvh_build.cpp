@@ -15,6 +15,7 @@
 // the other in pre-order.  The result is the same array, byte for byte, for any number of threads.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -42,10 +43,14 @@ struct Builder {
     std::vector<rt_bvh_node> nodes;       // pre-order; offset of a deferred subtree's placeholder = -(1 + subtree number)
     std::vector<Subtree> *deferred = nullptr;   // set on the top-level builder only
 
-    static float surface_area(const float *mn, const float *mx) {
+    // Half the surface area of a box, in the arithmetic of the reference's build: its Makefile's -ffast-math lets the
+    // compiler turn x y + x z + y z (src/bvh.cpp:249-257) into one fused x (y + z) + y z, and a split's cost (:259) into
+    // fma(fma(S1, 2 n1, (2 n0) S0), 1 / (2 S), 0.125).  The last bit matters wherever two splits cost the same on paper --
+    // the two opposite faces of any axis-aligned box -- because the first strictly cheaper split wins (:262-271).
+    static float half_area(const float *mn, const float *mx) {
         float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
         if (x < 0 || y < 0 || z < 0) return 0.0f;
-        return 2.f * (x * y + x * z + y * z);
+        return fmaf(x, y + z, y * z);
     }
 
     void make_leaf(int node, int start, int end) {
@@ -121,7 +126,8 @@ struct Builder {
             }
         }
         float cost[NB - 1];
-        const float parent_sa = surface_area(mn, mx);
+        const float parent_half = half_area(mn, mx);
+        const float inv_parent_sa = 1.0f / (parent_half + parent_half);
         for (int i = 0; i < NB - 1; ++i) {
             float mn0[3] = {0, 0, 0}, mx0[3] = {0, 0, 0}, mn1[3] = {0, 0, 0}, mx1[3] = {0, 0, 0};
             int c0 = 0, c1 = 0;
@@ -148,7 +154,8 @@ struct Builder {
                     c1 += buckets[j].count;
                     grow(mn1, mx1, init1, buckets[j]);
                 }
-            cost[i] = 0.125f + (c0 * surface_area(mn0, mx0) + c1 * surface_area(mn1, mx1)) / parent_sa;
+            const float n0 = (float)c0, n1 = (float)c1;
+            cost[i] = fmaf(fmaf(half_area(mn1, mx1), n1 + n1, (n0 + n0) * half_area(mn0, mx0)), inv_parent_sa, 0.125f);
         }
         float min_cost = cost[0];
         int split_bucket = 0;

@@ -7,16 +7,22 @@
 // and content; it records every file the scene pulled in (PLY meshes, images) with a 128-bit hash of its content, and
 // is used only while all of them still hash the same.  The arrays are mapped read-only and handed to rt_scene_create as
 // they lie in the file; the scene description built from a cache file is byte for byte the one a fresh load builds.
+// The header also carries a 128-bit hash of everything behind it (checked on every load: a truncated, damaged or edited
+// file falls back to the full load) and a stamp of the host sources the library was built from (the build passes their
+// hash as RT_HOST_SOURCE_STAMP), so a cache written by another ingest or tree builder is not used either.  The hash is not
+// cryptographic: the cache directory is trusted as far as the scene files themselves are.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <memory>
+#include <thread>
 
 #include "scene.h"
 
@@ -25,7 +31,10 @@ namespace rth {
 namespace {
 
 constexpr uint32_t CACHE_MAGIC = 0x43535452u;   // "RTSC"
-constexpr uint32_t CACHE_VERSION = 1;
+constexpr uint32_t CACHE_VERSION = 2;
+#ifndef RT_HOST_SOURCE_STAMP
+#define RT_HOST_SOURCE_STAMP __DATE__ " " __TIME__   // (a build that does not hash the sources: the time this file was compiled)
+#endif
 constexpr int N_SECTIONS = 13;
 
 struct Hash128 {
@@ -87,6 +96,37 @@ struct Mapping {
     Mapping &operator=(const Mapping &) = delete;
 };
 
+// Hash of a large block: 1 MiB pieces hashed on up to eight threads, the pieces' hashes folded in order (the result does
+// not depend on the number of threads).
+void hash_block(const uint8_t *p, size_t n, Hash128 &h) {
+    constexpr size_t PIECE = 1u << 20;
+    const size_t pieces = (n + PIECE - 1) / PIECE;
+    std::vector<Hash128> part(pieces);
+    size_t want = std::min<size_t>(8, pieces / 8);   // a thread is worth starting for eight pieces or more
+    want = std::min<size_t>(want, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned workers = (unsigned)std::max<size_t>(1, want);
+    auto run = [&](unsigned w) {
+        for (size_t i = w; i < pieces; i += workers) part[i].bytes(p + i * PIECE, std::min(PIECE, n - i * PIECE));
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 1; w < workers; ++w) pool.emplace_back(run, w);
+    run(0);
+    for (std::thread &t : pool) t.join();
+    for (const Hash128 &x : part) {
+        const uint64_t v[2] = {x.a, x.b};
+        h.words(v, 2);
+    }
+    const uint64_t len = n;
+    h.words(&len, 1);
+}
+
+uint64_t source_stamp() {
+    Hash128 h;
+    const char *s = RT_HOST_SOURCE_STAMP;
+    h.bytes(s, strlen(s));
+    return h.a ^ h.b;
+}
+
 bool hash_file(const std::string &path, Hash128 &h) {
     Mapping m(path);
     if (!m.ok) return false;
@@ -103,7 +143,11 @@ struct Header {
     float ambient_light[3], background_color[3];
     int32_t background_texture, is_probe;
     uint32_t struct_bytes[N_SECTIONS];   // sizeof of every record type when the file was written
+    uint64_t source_stamp;               // of the host sources that wrote the file
+    uint64_t body_bytes;                 // the file's size behind the header (64-byte aligned start) ...
+    uint64_t body_hash[2];               // ... and its hash
 };
+constexpr uint64_t BODY_START = (sizeof(Header) + 63) / 64 * 64;
 
 const uint32_t RECORD_BYTES[N_SECTIONS] = {sizeof(rt_triangle), sizeof(rt_instance), sizeof(rt_sphere), sizeof(rt_plane), sizeof(rt_material),
                                            sizeof(rt_texture),  sizeof(int32_t),     sizeof(rt_image),  sizeof(uint8_t),  sizeof(float),
@@ -172,8 +216,14 @@ bool scene_cache_load(const std::string &json_path, HostScene &out) {
     Header h;
     memcpy(&h, m.data, sizeof h);
     if (h.magic != CACHE_MAGIC || h.version != CACHE_VERSION || h.abi_version != RT_ABI_VERSION || h.n_sections != N_SECTIONS ||
-        h.json_hash[0] != json_hash[0] || h.json_hash[1] != json_hash[1])
+        h.json_hash[0] != json_hash[0] || h.json_hash[1] != json_hash[1] || h.source_stamp != source_stamp())
         return false;
+    if (m.size < BODY_START || h.body_bytes != m.size - BODY_START) return false;   // truncated, or longer than what was written
+    {
+        Hash128 body;
+        hash_block(m.data + BODY_START, (size_t)h.body_bytes, body);
+        if (body.a != h.body_hash[0] || body.b != h.body_hash[1]) return false;   // damaged or edited
+    }
     const void *section[N_SECTIONS];
     uint64_t count[N_SECTIONS];
     for (int k = 0; k < N_SECTIONS; ++k) {
@@ -279,7 +329,8 @@ void scene_cache_store(const std::string &json_path, const HostScene &scene) {
     Header h{};
     h.magic = CACHE_MAGIC, h.version = CACHE_VERSION, h.abi_version = RT_ABI_VERSION, h.n_sections = N_SECTIONS;
     h.json_hash[0] = json_hash[0], h.json_hash[1] = json_hash[1];
-    uint64_t at = (sizeof(Header) + 63) / 64 * 64;
+    h.source_stamp = source_stamp();
+    uint64_t at = BODY_START;
     for (int k = 0; k < N_SECTIONS; ++k) {
         h.struct_bytes[k] = RECORD_BYTES[k];
         h.section_offset[k] = at;
@@ -321,27 +372,30 @@ void scene_cache_store(const std::string &json_path, const HostScene &scene) {
     memcpy(h.background_color, scene.background_color, sizeof h.background_color);
     h.background_texture = scene.background_texture, h.is_probe = scene.is_probe;
 
-    // written under a private name and renamed into place: a reader never sees half a file
+    // The body as it will lie in the file (sections at their offsets, zero padding between, the tail last); hashed, then
+    // written under a private name and renamed into place: a reader never sees half a file.
+    h.body_bytes = h.tail_offset + h.tail_bytes - BODY_START;
+    std::vector<uint8_t> body;
+    try {
+        body.assign((size_t)h.body_bytes, 0);
+    } catch (const std::bad_alloc &) {
+        return;   // no memory for a second copy of the scene: no cache for it
+    }
+    for (int k = 0; k < N_SECTIONS; ++k)
+        if (h.section_bytes[k]) memcpy(body.data() + (h.section_offset[k] - BODY_START), section[k], (size_t)h.section_bytes[k]);
+    if (!tail.empty()) memcpy(body.data() + (h.tail_offset - BODY_START), tail.data(), tail.size());
+    {
+        Hash128 bh;
+        hash_block(body.data(), body.size(), bh);
+        h.body_hash[0] = bh.a, h.body_hash[1] = bh.b;
+    }
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;
     bool ok = fwrite(&h, sizeof h, 1, f) == 1;
     static const uint8_t zeros[64] = {};
-    uint64_t pos = sizeof h;
-    auto pad_to = [&](uint64_t target) {
-        while (ok && pos < target) {
-            const size_t n = (size_t)std::min<uint64_t>(64, target - pos);
-            ok = fwrite(zeros, 1, n, f) == n;
-            pos += n;
-        }
-    };
-    for (int k = 0; k < N_SECTIONS && ok; ++k) {
-        pad_to(h.section_offset[k]);
-        if (h.section_bytes[k]) ok = ok && fwrite(section[k], 1, (size_t)h.section_bytes[k], f) == h.section_bytes[k];
-        pos += h.section_bytes[k];
-    }
-    pad_to(h.tail_offset);
-    if (!tail.empty()) ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+    if (ok && BODY_START > sizeof h) ok = fwrite(zeros, 1, BODY_START - sizeof h, f) == BODY_START - sizeof h;
+    if (ok && !body.empty()) ok = fwrite(body.data(), 1, body.size(), f) == body.size();
     ok = fclose(f) == 0 && ok;
     if (ok)
         std::filesystem::rename(tmp, path, ec);

@@ -13,10 +13,13 @@ For every scene the reference's own parser, BVH and integrators produce
   bvh_bounds            node bounds (trees of <= 4096 nodes)
 The reference's random numbers cannot be seeded, so stochastic scenes are rendered several times
 and averaged; exact scenes once.
+`pt1m` is the benchmark's path-traced scene (1 008 202 triangles) at 480x270 and 16 samples per pixel: the image as a
+stochastic scene, and ids / t from the same scene file with one sample per pixel (the pixel-centre ray).
 """
 import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 import sys
 import tempfile
 
@@ -54,6 +57,8 @@ def main():
         jobs = [(name, builder(os.path.join(tmp, "scenes")), kind) for name, (builder, kind) in S.SCENES.items()]
         jobs.append(("simple", os.path.join(ROOT, "scenes", "simple.json"), "exact"))
         jobs.append(("mesh70k", scenegen.write_mesh_scene(os.path.join(tmp, "scenes"), name="mesh70k", n=188, width=320, height=180), "exact"))
+        if "pt1m" in sys.argv[1:] or not sys.argv[1:]:
+            jobs.append(("pt1m", scenegen.write_path_traced_scene(os.path.join(tmp, "scenes"), name="pt1m", n=710, width=480, height=270, spp=16), "stochastic"))
         only = set(sys.argv[1:])
         for name, path, kind in jobs:
             if only and name not in only:
@@ -63,15 +68,22 @@ def main():
                 ids, t, hdr, bvh = run_ref(path, prefix)
                 np.savez_compressed(os.path.join(HERE, name + ".npz"), ids=ids, t=t, hdr=hdr, **bvh)
             else:
-                imgs = []
-                for _ in range(REPEATS):
-                    _, _, hdr, bvh = run_ref(path, prefix)
-                    imgs.append(hdr.astype(np.float64))
-                imgs = np.stack(imgs)
+                def one(k):
+                    return run_ref(path, f"{prefix}_{k}")
+                with ThreadPoolExecutor(max_workers=4) as pool:   # ref_dump renders on one thread
+                    runs = list(pool.map(one, range(REPEATS)))
+                bvh = runs[0][3]
+                imgs = np.stack([r[2].astype(np.float64) for r in runs])
                 mean = imgs.mean(axis=0)
                 sem = imgs.std(axis=0, ddof=1) / np.sqrt(REPEATS)
+                extra = {}
+                if name == "pt1m":   # primary hits of the pixel-centre rays: the same scene at one sample per pixel
+                    one_spp = scenegen.write_path_traced_scene(os.path.join(tmp, "scenes"), name="pt1m_1spp", n=710, width=480, height=270, spp=1)
+                    subprocess.check_call([REF_DUMP, one_spp, prefix + "_ids", "0", "noimage"], stdout=subprocess.DEVNULL, cwd=tmp)
+                    extra["ids"] = np.fromfile(prefix + "_ids.ids.i32", dtype=np.int32).reshape(-1, 2)
+                    extra["t"] = np.fromfile(prefix + "_ids.t.f32", dtype=np.float32)
                 np.savez_compressed(os.path.join(HERE, name + ".npz"), hdr=mean.astype(np.float32), hdr_std=sem.astype(np.float32),
-                                    repeats=np.array(REPEATS), **bvh)
+                                    repeats=np.array(REPEATS), **bvh, **extra)
             print(name, kind, "done")
 
 

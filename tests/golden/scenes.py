@@ -369,6 +369,44 @@ def emitters_scene(out_dir):
     return dump(out_dir, "emitters", sc)
 
 
+def cornell_scene(out_dir):
+    """A closed box with diffuse walls lit by nothing but a mesh emitter in the ceiling (two emitter triangles), path
+    traced with next-event estimation: every direct-light sample is a shadow ray that ends ON an emitter triangle, the
+    case in which the reference's test `t < distance - epsilon` (src/ray_trace.cpp:232-241, src/lights.cpp:340-386)
+    decides between light and shadow at rounding level."""
+    white = {"_id": "1", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0.73 0.73 0.73", "SpecularReflectance": "0 0 0"}
+    red = {"_id": "2", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0.65 0.05 0.05", "SpecularReflectance": "0 0 0"}
+    green = {"_id": "3", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0.12 0.45 0.15", "SpecularReflectance": "0 0 0"}
+    black = {"_id": "4", "AmbientReflectance": "0 0 0", "DiffuseReflectance": "0 0 0", "SpecularReflectance": "0 0 0"}
+    box = [(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)]
+    lamp = [(-0.3, 1.995, -0.3), (0.3, 1.995, -0.3), (0.3, 1.995, 0.3), (-0.3, 1.995, 0.3)]
+    block = [(x * 0.3 + 0.35, y * 0.6, z * 0.3 - 0.2) for x, y, z in CUBE_V]
+    verts = verts_str(box + lamp + block + [(-0.45, 0.35, 0.25)])
+    objects = {"Mesh": [{"_id": "1", "Material": "1", "Faces": {"_data": "1 4 3  1 3 2  5 6 7  5 7 8  1 2 6  1 6 5"}},   # floor, ceiling, back wall
+                        {"_id": "2", "Material": "2", "Faces": {"_data": "1 5 8  1 8 4"}},                             # left wall
+                        {"_id": "3", "Material": "3", "Faces": {"_data": "2 3 7  2 7 6"}},                             # right wall
+                        {"_id": "4", "Material": "1", "Faces": {"_data": faces_str(CUBE_F, 12)}}],
+               "LightMesh": {"_id": "5", "Material": "4", "Radiance": "18 15 10", "Faces": {"_data": "9 10 11  9 11 12"}},
+               "Sphere": {"_id": "1", "Material": "1", "Center": "21", "Radius": "0.35"}}
+    cam = camera("cornell.exr", res=(64, 64), pos="0 1 3.4", gaze_point="0 1 0", fovy="40", NumSamples="64", Renderer="PathTracing",
+                 RendererParams="ImportanceSampling NextEventEstimation RussianRoulette", MinRecursionDepth="2")
+    return dump(out_dir, "cornell", scene(cam, {"AmbientLight": "0 0 0"}, [white, red, green, black], verts, objects, MaxRecursionDepth="4"))
+
+
+def meshlight_scene(out_dir):
+    """The same box under recursive ray tracing: no emission term, no indirect light, so every lit pixel is the sum of
+    its 2 x 16 shadow rays towards samples ON the emitter's triangles -- the image is the direct measure of how often
+    such a ray counts as blocked by the emitter itself (src/ray_trace.cpp:232-241)."""
+    path = cornell_scene(out_dir)
+    doc = json.load(open(path))
+    cam = doc["Scene"]["Cameras"]["Camera"]
+    for k in ("Renderer", "RendererParams", "MinRecursionDepth"):
+        cam.pop(k)
+    cam["NumSamples"] = "16"
+    cam["ImageName"] = "meshlight.exr"
+    return dump(out_dir, "meshlight", doc)
+
+
 def pathtrace_env_scene(out_dir):
     """Path tracing under an environment map (cosine-sampled light + background), NEE on."""
     os.makedirs(out_dir, exist_ok=True)
@@ -456,6 +494,8 @@ SCENES = {
     "pathtrace": (pathtrace_scene, "stochastic"),
     "pt_uniform": (pathtrace_uniform_scene, "stochastic"),
     "emitters": (emitters_scene, "stochastic"),
+    "cornell": (cornell_scene, "stochastic"),
+    "meshlight": (meshlight_scene, "stochastic"),
     "pt_env": (pathtrace_env_scene, "stochastic"),
     "env_probe": (env_probe_scene, "stochastic"),
     "env_uniform": (env_uniform_scene, "stochastic"),

@@ -1,6 +1,6 @@
 """GPU parity: the HIP rendering core (through the C ABI) against the CPU oracle on the same inputs.
 
-Bar: primary-hit identities (shape, instance id) and hit distances bit-exact; images within the
+Bar: primary-hit identities (shape, instance id) and hit distances bit-exact; EVERY pixel of an image within the
 relative tolerance stated per test (the device walks the path tree with a throughput-carrying
 stack while the oracle recurses, so sums differ by float re-association only)."""
 import ctypes as C
@@ -54,7 +54,7 @@ def test_device_arithmetic_is_bit_identical_to_host():
     assert np.array_equal(out, ref)
 
 
-def _check_scene(path, tol, frac_ok=0.0):
+def _check_scene(path, tol):
     sc = R.Scene(path)
     cam = sc.camera(0)
     orc = Oracle(sc)
@@ -71,8 +71,7 @@ def _check_scene(path, tol, frac_ok=0.0):
     assert (so.primary_rays, so.shadow_rays, so.secondary_rays) == (sg.primary_rays, sg.shadow_rays, sg.secondary_rays)
     assert so.nodes_visited == sg.nodes_visited and so.triangle_tests == sg.triangle_tests and so.sphere_tests == sg.sphere_tests
     err = rel_err(img1, img0).max(axis=2)
-    bad = (err > tol).mean()
-    assert bad <= frac_ok, f"{(err > tol).sum()} pixels over tol {tol}; max {err.max()}"
+    assert err.max() <= tol, f"{(err > tol).sum()} pixels over tol {tol}; max {err.max()}"   # every pixel: no outlier allowance
     return sc, cam, img1, sg
 
 
@@ -92,6 +91,8 @@ from golden import scenes as GS  # noqa: E402
 def test_feature_scene_matches_oracle(name, scene_dir):
     """Every feature scene (materials, textures, BRDFs, transforms/instancing, lights, distribution effects, path
     tracing) under the shared counter-based random numbers: identical ray counts and traversal work, primary hits
-    bit-exact, image within 2e-4 relative (5e-3 for the few pixels where a re-associated sum flips a clamp)."""
+    bit-exact, every pixel value within 1e-5 relative (floor 1/255).  Measured over the scenes (tools/outlier_survey.py):
+    the largest difference is 4e-7, in the path-traced frames, whose samples are summed in another order; the frames
+    without branching paths are equal bit for bit."""
     builder, kind = GS.SCENES[name]
-    _check_scene(builder(scene_dir), 2e-4, frac_ok=2e-3)
+    _check_scene(builder(scene_dir), 1e-5)

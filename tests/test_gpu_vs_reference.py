@@ -7,7 +7,7 @@ import pytest
 
 import raytracer_amd as R
 from golden import scenes as S
-from test_oracle_vs_reference import EXACT, STOCHASTIC, load, scene_path
+from test_oracle_vs_reference import EXACT, STOCHASTIC, check_pt1m_image, check_pt1m_primary_hits, load, pt1m_scene, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -47,3 +47,19 @@ def test_stochastic_scene_against_reference(name, scene_dir, repo_root):
     off = (z > 6.0) & (np.abs(mean - ref) > 0.05 * np.maximum(np.abs(ref), 1.0 / 255.0))
     assert np.mean(off) <= 2e-3, f"{np.mean(off):.4f} of values are more than 6 sigma and 5 % from the reference"
     assert np.median(z) < 1.5
+
+
+def test_benchmark_scene_against_reference(scene_dir, monkeypatch):
+    """The headline benchmark's scene (1 008 202 triangles) at 480x270: primary hits of the pixel-centre rays and the
+    16-sample path-traced image against the fixture rendered by the compiled reference (tests/golden/pt1m.npz), timed
+    render path (wide tree, shared shadow rays)."""
+    monkeypatch.setenv("RT_WIDE_NODES", "1")
+    g = load("pt1m")
+    sc1 = pt1m_scene(scene_dir, spp=1)
+    shape, ids, t, _ = R.Renderer(sc1).trace_primary(sc1.camera(0))
+    check_pt1m_primary_hits(shape, ids, t, g)
+    sc = pt1m_scene(scene_dir)
+    ren = R.Renderer(sc)
+    reps = 12
+    imgs = np.stack([ren.render(sc.camera(0, seed=2000 + k))[0].astype(np.float64) for k in range(reps)])
+    check_pt1m_image(imgs.mean(axis=0), imgs.std(axis=0, ddof=1) / np.sqrt(reps), g)

@@ -140,3 +140,55 @@ def test_stochastic_scene_against_reference(name, scene_dir, repo_root):
     off = (z > 6.0) & (np.abs(mean - ref) > 0.05 * np.maximum(np.abs(ref), 1.0 / 255.0))
     assert np.mean(off) <= 2e-3, f"{np.mean(off):.4f} of values are more than 6 sigma and 5 % from the reference"
     assert np.median(z) < 1.5
+
+
+def pt1m_scene(scene_dir, spp=16):
+    return R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt1m", name=f"pt1m_{spp}", n=710, width=480, height=270, spp=spp))
+
+
+def check_pt1m_primary_hits(shape, ids, t, g):
+    ref_ids, ref_t = g["ids"], g["t"]
+    assert int((ref_ids[:, 0] >= 0).sum()) == 75766
+    mismatch = (shape != ref_ids[:, 0]) | (ids != ref_ids[:, 1])
+    assert mismatch.mean() <= 1e-4, f"{mismatch.sum()} of {len(shape)} primary-hit ids differ from the reference's"
+    assert np.array_equal(shape >= 0, ref_ids[:, 0] >= 0) or ((shape >= 0) != (ref_ids[:, 0] >= 0)).sum() <= 2, "hit / miss flips"
+    both = (shape >= 0) & ~mismatch
+    assert np.mean(np.abs(t[both] - ref_t[both]) > 2e-4 * np.maximum(1.0, ref_t[both])) <= 1e-3
+
+
+def check_pt1m_image(mean, sem, g):
+    ref, ref_sem = g["hdr"].astype(np.float64), g["hdr_std"].astype(np.float64)
+    assert abs(mean.mean() - ref.mean()) <= 0.02 * abs(ref.mean()), (mean.mean(), ref.mean())
+    sigma = np.sqrt(sem ** 2 + ref_sem ** 2) + 1e-3 * np.maximum(np.abs(ref), 1.0 / 255.0)
+    z = np.abs(mean - ref) / sigma
+    off = (z > 6.0) & (np.abs(mean - ref) > 0.05 * np.maximum(np.abs(ref), 1.0 / 255.0))
+    assert np.mean(off) <= 2e-3, f"{np.mean(off):.4f} of values are more than 6 sigma and 5 % from the reference"
+    assert np.median(z) < 1.5
+
+
+def test_benchmark_scene_tree_is_the_references(scene_dir):
+    """The 1 008 202-triangle scene of the headline benchmark: the host's SAH tree (1.7 M nodes, built by the thread pool)
+    is the tree the reference builds -- same nodes in the same order, same leaf contents in the same order, same bounds
+    (SHA-256 over the byte stream of the reference's arrays, src/bvh.cpp:41-344; 16-bit leaf counts src/bvh.h:20 and the
+    nth_element fallbacks included) -- and the pixel-centre rays of a 480x270 frame find the reference's primitives."""
+    g = load("pt1m")
+    sc = pt1m_scene(scene_dir, spp=1)
+    assert sc.desc.n_triangles == 1008202
+    check_bvh(sc, g, "pt1m")
+    bounds, meta, prims = sc.bvh_arrays()
+    head = np.array([len(bounds), len(prims)], dtype=np.int32).tobytes()
+    assert len(bounds) > 1_500_000
+    shape, ids, t, _ = Oracle(sc).trace_primary(sc.camera(0))
+    check_pt1m_primary_hits(shape, ids, t, g)
+
+
+def test_benchmark_scene_image_against_reference(scene_dir):
+    """The same scene path traced at 480x270 x 16 samples (importance sampling, next-event estimation, Russian roulette,
+    depth 4): the oracle's image against the mean of twelve runs of the reference, with the bars of the stochastic
+    fixtures."""
+    g = load("pt1m")
+    sc = pt1m_scene(scene_dir)
+    orc = Oracle(sc)
+    reps = 4
+    imgs = np.stack([orc.render(sc.camera(0, seed=1000 + k))[0].astype(np.float64) for k in range(reps)])
+    check_pt1m_image(imgs.mean(axis=0), imgs.std(axis=0, ddof=1) / np.sqrt(reps), g)

@@ -88,6 +88,31 @@ def test_damaged_cache_file_is_ignored(tmp_path, monkeypatch):
         assert open(tmp_path / "cache" / name, "rb").read() == full
 
 
+def test_cache_file_with_changed_bytes_is_ignored(tmp_path, monkeypatch):
+    """The header carries a hash of everything behind it: one flipped bit anywhere in the arrays (a triangle, a tree node, a
+    texel, the cameras), a byte appended, or a file written by a library built from other host sources (its stamp in the
+    header) makes the load fall back to parsing, and the entry is rewritten."""
+    monkeypatch.setenv("RT_SCENE_CACHE", str(tmp_path / "cache"))
+    path = GS.SCENES["textures"][0](str(tmp_path / "scene"))
+    fresh = snapshot(R.Scene(path))
+    (name,) = cache_files(tmp_path / "cache")
+    file = tmp_path / "cache" / name
+    full = open(file, "rb").read()
+    assert R.Scene(path).timings()["bvh_ms"] == 0          # served from the cache as it stands
+    n = len(full)
+    damaged = []
+    for at in (n // 4, n // 2, 3 * n // 4, n - 1, 1024):
+        b = bytearray(full)
+        b[at] ^= 0x10
+        damaged.append(bytes(b))
+    damaged.append(full + b"\0")
+    for d in damaged:
+        open(file, "wb").write(d)
+        sc = R.Scene(path)
+        assert sc.timings()["bvh_ms"] > 0 and snapshot(sc) == fresh
+        assert open(file, "rb").read() == full
+
+
 def test_cached_load_of_the_million_triangle_scene_is_fast(tmp_path, monkeypatch):
     """What the cache is for: the benchmark scene (1 008 202 triangles, 1.7 M BVH nodes, 171 MB of arrays) loads from
     its cache file in well under 50 ms (about 7 ms when the file is in the page cache), against 0.7 s for a fresh load."""
