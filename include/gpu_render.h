@@ -316,7 +316,12 @@ int32_t rt_scene_plain_shading(const rt_scene *scene);
  *                       exchange by device-to-device copies instead of RCCL, which allows one rank per device.
  *   rt_comm_unique_id + rt_comm_init_rank
  *                       ranks are processes: rank 0 makes the id (RT_COMM_ID_BYTES bytes), the launcher hands it to
- *                       every rank, each calls rt_comm_init_rank with its device current (ncclCommInitRank). */
+ *                       every rank, each calls rt_comm_init_rank with its device current (ncclCommInitRank).
+ * A frame fails as a whole.  Before the tiles travel the ranks agree on one status word (an all-reduce of one integer), so
+ * a rank that could not render its tiles still takes part in every step the others wait in: it returns its own error,
+ * every other rank returns 12 ("a peer rank failed"), and no rank is left waiting.  The communicator stays usable.
+ * RCCL is opened at run time (dlopen) when the first communicator is made; RT_RCCL_LIB=<path> names the library to open
+ * in place of the one beside the HIP runtime. */
 /* Host-only: the layout of the gather.  tiles_of_rank_out[r] = tiles rank r renders; tile_slot_out[ty*tiles_x + tx] = the
  * tile's slot (units of 32*32*3 floats) in the root's receive buffer, where the tiles of rank r follow those of ranks
  * 0 .. r-1 and a rank's tiles stand in row-major order, the order in which it packs them.  Touches no GPU. */

@@ -9,6 +9,11 @@
 // Ranks that share a device -- a rehearsal of the N-rank path on one GPU, which RCCL does not allow in one
 // communicator -- exchange through device-to-device copies inside the process instead; packing, tile lists and the
 // unpack kernel are the same.
+//
+// A frame fails as a whole: before the tiles travel the ranks agree on one status word (an all-reduce of one integer on
+// the RCCL transport, the meeting point's flag on the local one), so a rank whose render failed, or that could not get
+// its buffers, still takes part in every step its peers wait in, and every rank of the frame returns an error (its own,
+// or 12 for a peer's) instead of some of them waiting for ever.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -29,6 +34,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -38,7 +44,11 @@ RcclApi *rccl_api() {
     std::call_once(once, [] {
         // first the RCCL that belongs to the HIP runtime this process runs on (the one in the runtime's own directory: a
         // process may hold a second ROCm installation, e.g. the one a Python package ships), then the loader's choice
+        // (RT_RCCL_LIB=<path> goes first: a site's own build of the library, or the tests' stand-in that moves the data
+        // between the threads of one process so that the exchange below runs with several ranks on one GPU)
         std::vector<std::string> names;
+        if (const char *e = getenv("RT_RCCL_LIB"))
+            if (*e) names.push_back(e);
         Dl_info info;
         if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
             std::string dir(info.dli_fname);
@@ -64,9 +74,10 @@ RcclApi *rccl_api() {
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.Send = (decltype(api.Send))sym("ncclSend");
         api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send ||
-            !api.Recv || !api.GetErrorString) {
+            !api.Recv || !api.AllReduce || !api.GetErrorString) {
             dlclose(api.handle);
             api.handle = nullptr;
         }
@@ -91,7 +102,8 @@ struct LocalGroup {
     int arrived = 0, left = 0;
     unsigned long long round = 0;
     std::vector<const float *> packed;   // per rank: its finished packed buffer (device memory)
-    int failed = 0;
+    int failed = 0;                      // a rank of the round that is meeting has failed
+    int last_failed = 0;                 // the finished round's verdict, for the peers that wake up after it
 };
 
 }  // namespace
@@ -113,6 +125,7 @@ struct rt_comm {
     size_t gathered_room = 0;
     float *frame = nullptr;                  // root: the frame on the device when the caller's buffer is host memory
     size_t frame_room = 0;
+    int *status = nullptr;                   // RCCL transport, device: the frame's status word (made with the communicator)
 };
 
 namespace {
@@ -226,6 +239,12 @@ int rt_comm_init_rank(const void *id, int32_t id_bytes, int32_t rank, int32_t wo
         ncclUniqueId uid;
         memcpy(&uid, id, sizeof uid);
         RCCL_OK(api, api->CommInitRank(&c->nccl, world, uid, rank));
+        if (hipMalloc((void **)&c->status, 2 * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)api->CommDestroy(c->nccl);
+            g_error = "rt_comm_init_rank: no device memory for the status word";
+            return 2;
+        }
     }
     *out = c.release();
     return 0;
@@ -254,6 +273,8 @@ int rt_comm_init_all(int32_t n, const int32_t *devices, rt_comm **comms_out) {
         group->world = n;
         group->packed.assign((size_t)n, nullptr);
     }
+    int before = 0;
+    (void)hipGetDevice(&before);
     for (int r = 0; r < n; ++r) {
         rt_comm *c = new rt_comm();
         c->rank = r;
@@ -262,7 +283,17 @@ int rt_comm_init_all(int32_t n, const int32_t *devices, rt_comm **comms_out) {
         c->nccl = nccl[(size_t)r];
         c->local = group;
         comms_out[r] = c;
+        if (c->nccl && (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&c->status, 2 * sizeof(int)) != hipSuccess)) {
+            (void)hipGetLastError();
+            for (int k = 0; k <= r; ++k) rt_comm_destroy(comms_out[k]), comms_out[k] = nullptr;
+            for (int k = r + 1; k < n; ++k)
+                if (nccl[(size_t)k]) (void)rccl_api()->CommDestroy(nccl[(size_t)k]);
+            (void)hipSetDevice(before);
+            g_error = "rt_comm_init_all: no device memory for the status word";
+            return 2;
+        }
     }
+    (void)hipSetDevice(before);
     return 0;
 }
 
@@ -271,88 +302,124 @@ void rt_comm_destroy(rt_comm *c) {
     (void)hipSetDevice(c->device);
     if (c->nccl)
         if (RcclApi *api = rccl_api()) (void)api->CommDestroy(c->nccl);
-    for (void *p : {(void *)c->tile_slot, (void *)c->packed, (void *)c->gathered, (void *)c->frame})
+    for (void *p : {(void *)c->tile_slot, (void *)c->packed, (void *)c->gathered, (void *)c->frame, (void *)c->status})
         if (p) (void)hipFree(p);
     delete c;
 }
 
 int rt_render_gather(rt_scene *s, rt_comm *c, const rt_camera_desc *cam, float *hdr_out, rt_stats *stats) {
-    if (!s || !c || !cam || (c->rank == 0 && !hdr_out)) {
+    if (!s || !c || !cam) {   // (nothing to take part in the exchange with)
         g_error = "rt_render_gather: null argument";
         return 1;
     }
-    if (s->device != c->device) {
+    // From here on every path reaches the point where the ranks agree on the frame's status: `rc` is this rank's own.
+    int rc = 0;
+    std::string own_error;
+    auto failed = [&](int code) {
+        if (code && !rc) rc = code, own_error = g_error;
+        return code != 0;
+    };
+    if (c->rank == 0 && !hdr_out) {
+        g_error = "rt_render_gather: null argument";
+        failed(1);
+    } else if (s->device != c->device) {
         g_error = "rt_render_gather: the scene and the communicator are on different devices";
-        return 1;
-    }
-    if (cam->resx < 1 || cam->resy < 1) {
+        failed(1);
+    } else if (cam->resx < 1 || cam->resy < 1) {
         g_error = "invalid camera: resolution and sample count must be positive";
-        return 4;
+        failed(4);
     }
     auto t0 = std::chrono::high_resolution_clock::now();
-    HIP_OK(hipSetDevice(s->device));
-    if (int rc = comm_layout(c, cam->resx, cam->resy)) return rc;
+    HIP_OK(hipSetDevice(c->device));
     const size_t tile_floats = (size_t)TILE * TILE * 3;
-    const size_t mine = (size_t)c->tiles_of_rank[(size_t)c->rank] * tile_floats;
-    const size_t all = c->first_tile_of_rank[(size_t)c->world] * tile_floats;
-    const size_t frame_floats = (size_t)cam->resx * cam->resy * 3;
-    const int tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
-    float *target;   // where this rank's tiles are rendered: straight into the root's gather buffer, or the send buffer
-    if (c->rank == 0) {
-        if (int rc = comm_buffer(c, c->gathered, c->gathered_room, all)) return rc;
-        target = c->gathered + c->first_tile_of_rank[0] * tile_floats;
-    } else {
-        if (int rc = comm_buffer(c, c->packed, c->packed_room, mine)) return rc;
-        target = c->packed;
-    }
+    size_t mine = 0, all = 0, frame_floats = 0;
+    int tiles_x = 0, tiles_y = 0;
     float kernel_ms = 0.f;
-    int rc = render_tiles(s, cam, c->rank, c->world, target, true, kernel_ms);   // returns with the stream drained
-    // ---- the exchange: every rank's packed tiles to the root ----
-    if (c->nccl) {
-        if (rc) return rc;   // (the peers then wait in their collective: a failed render is fatal for the frame)
-        RcclApi *api = rccl_api();
-        RCCL_OK(api, api->GroupStart());
+    if (!rc && !failed(comm_layout(c, cam->resx, cam->resy))) {
+        mine = (size_t)c->tiles_of_rank[(size_t)c->rank] * tile_floats;
+        all = c->first_tile_of_rank[(size_t)c->world] * tile_floats;
+        frame_floats = (size_t)cam->resx * cam->resy * 3;
+        tiles_x = (cam->resx + TILE - 1) / TILE, tiles_y = (cam->resy + TILE - 1) / TILE;
+        float *target = nullptr;   // where this rank's tiles are rendered: straight into the root's gather buffer, or the send buffer
         if (c->rank == 0) {
-            for (int r = 1; r < c->world; ++r)
-                if (c->tiles_of_rank[(size_t)r])
-                    RCCL_OK(api, api->Recv(c->gathered + c->first_tile_of_rank[(size_t)r] * tile_floats, (size_t)c->tiles_of_rank[(size_t)r] * tile_floats, ncclFloat, r,
-                                           c->nccl, s->stream));
-        } else if (mine) {
-            RCCL_OK(api, api->Send(c->packed, mine, ncclFloat, 0, c->nccl, s->stream));
+            if (!failed(comm_buffer(c, c->gathered, c->gathered_room, all))) target = c->gathered + c->first_tile_of_rank[0] * tile_floats;
+        } else {
+            if (!failed(comm_buffer(c, c->packed, c->packed_room, mine))) target = c->packed;
         }
-        RCCL_OK(api, api->GroupEnd());
+        if (!rc) failed(render_tiles(s, cam, c->rank, c->world, target, true, kernel_ms));   // returns with the stream drained
+    }
+    auto verdict_of = [&](int any_failed) {   // the frame's verdict as this rank's return value
+        if (!any_failed) return 0;
+        if (rc) {
+            g_error = own_error;
+            return rc;
+        }
+        g_error = "rt_render_gather: a peer rank failed to render its tiles";
+        return 12;
+    };
+    // ---- the exchange: one status word, then every rank's packed tiles to the root ----
+    if (c->nccl) {
+        RcclApi *api = rccl_api();
+        if (c->world > 1) {
+            int status = rc ? 1 : 0;
+            HIP_OK(hipMemcpyAsync(c->status, &status, sizeof status, hipMemcpyHostToDevice, s->stream));
+            RCCL_OK(api, api->AllReduce(c->status, c->status + 1, 1, ncclInt32, ncclMax, c->nccl, s->stream));
+            HIP_OK(hipMemcpyAsync(&status, c->status + 1, sizeof status, hipMemcpyDeviceToHost, s->stream));
+            HIP_OK(hipStreamSynchronize(s->stream));
+            if (status) return verdict_of(1);
+        } else if (rc) {
+            return verdict_of(1);
+        }
+        RCCL_OK(api, api->GroupStart());
+        ncclResult_t r = ncclSuccess;
+        const char *what = "";
+        if (c->rank == 0) {
+            for (int k = 1; k < c->world && r == ncclSuccess; ++k)
+                if (c->tiles_of_rank[(size_t)k]) {
+                    r = api->Recv(c->gathered + c->first_tile_of_rank[(size_t)k] * tile_floats, (size_t)c->tiles_of_rank[(size_t)k] * tile_floats, ncclFloat, k, c->nccl,
+                                  s->stream);
+                    what = "ncclRecv";
+                }
+        } else if (mine) {
+            r = api->Send(c->packed, mine, ncclFloat, 0, c->nccl, s->stream);
+            what = "ncclSend";
+        }
+        const ncclResult_t closed = api->GroupEnd();   // (also after a failed call inside: the group must not stay open on this thread)
+        if (r != ncclSuccess || closed != ncclSuccess) {
+            g_error = std::string(r != ncclSuccess ? what : "ncclGroupEnd") + ": " + api->GetErrorString(r != ncclSuccess ? r : closed);
+            return 11;
+        }
     } else if (c->local) {
         LocalGroup &g = *c->local;
         std::unique_lock<std::mutex> lk(g.m);
         const unsigned long long round = g.round;
-        g.packed[(size_t)c->rank] = c->rank == 0 ? nullptr : c->packed;
+        g.packed[(size_t)c->rank] = c->rank == 0 || rc ? nullptr : c->packed;
         if (rc) g.failed = 1;
         if (++g.arrived == g.world) g.cv.notify_all();
+        int any_failed = 0;
         if (c->rank == 0) {
             g.cv.wait(lk, [&] { return g.arrived == g.world; });
-            const int failed = g.failed;
+            any_failed = g.failed;
             hipError_t e = hipSuccess;
-            for (int r = 1; r < c->world && !failed && e == hipSuccess; ++r)
+            for (int r = 1; r < c->world && !any_failed && e == hipSuccess; ++r)
                 if (c->tiles_of_rank[(size_t)r])
                     e = hipMemcpyAsync(c->gathered + c->first_tile_of_rank[(size_t)r] * tile_floats, g.packed[(size_t)r],
                                        (size_t)c->tiles_of_rank[(size_t)r] * tile_floats * sizeof(float), hipMemcpyDeviceToDevice, s->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
             g.arrived = 0;
             g.failed = 0;
+            g.last_failed = any_failed;
             ++g.round;          // the peers' buffers are free again
             g.cv.notify_all();
             lk.unlock();
-            if (failed && !rc) {
-                g_error = "rt_render_gather: a peer rank failed to render its tiles";
-                return 12;
-            }
-            HIP_OK(e);
+            if (!any_failed) HIP_OK(e);
         } else {
             g.cv.wait(lk, [&] { return g.round != round; });
+            any_failed = g.last_failed;   // (the next round cannot end before this rank has arrived in it)
         }
-        if (rc) return rc;
+        if (any_failed) return verdict_of(1);
     } else if (rc) {
-        return rc;
+        return verdict_of(1);
     }
     // ---- root: tiles to their places in the frame ----
     if (c->rank == 0) {

@@ -5,8 +5,10 @@
 // the reference (src/main.cpp:437-555) is replaced by one rt_render() call per camera; the threading
 // arguments are still parsed and validated so existing invocations keep working, but they no longer
 // select anything — the GPU schedules the pixels.  RT_GPU=<index> picks the device; without it the files of a
-// directory are spread over all visible GPUs (frame -> GPU).  RT_GPUS=<n> makes the first n GPUs a team that renders
-// every frame together: each GPU its share of the 32x32 tiles, gathered on the first over RCCL (rt_render_gather).
+// directory are spread over all visible GPUs (frame -> GPU).  RT_GPUS=<k> makes teams of k GPUs that render a frame
+// together: each GPU its share of the 32x32 tiles, gathered on the team's first over RCCL (rt_render_gather); the teams
+// take frames in turn beside each other, and the frames left over when fewer remain than there are teams are rendered
+// by all GPUs regrouped into that many teams (frame-and-tile parallel: no GPU idles while a frame is left).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -143,45 +145,105 @@ static void job_printf(FileJob &job, const char *fmt, ...) {
     job.log += buf;
 }
 
+// GPUs that render a frame together: the first device leads (it receives the frame), the others run beside it.
+struct Team {
+    std::vector<int> devices;
+    std::vector<rt_comm *> comms;   // one per device when the team has more than one
+};
+
+// `gpus` cut into teams of `size` (the last one takes what is left).
+static std::vector<Team> make_teams(const std::vector<int> &gpus, size_t size) {
+    std::vector<Team> teams;
+    for (size_t at = 0; at < gpus.size(); at += size) {
+        Team t;
+        t.devices.assign(gpus.begin() + at, gpus.begin() + std::min(gpus.size(), at + size));
+        teams.push_back(std::move(t));
+    }
+    return teams;
+}
+
+// `gpus` spread over `n` teams as evenly as they go (n <= gpus.size()).
+static std::vector<Team> spread_teams(const std::vector<int> &gpus, size_t n) {
+    std::vector<Team> teams(n);
+    size_t at = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const size_t take = gpus.size() / n + (k < gpus.size() % n ? 1 : 0);
+        teams[k].devices.assign(gpus.begin() + at, gpus.begin() + at + take);
+        at += take;
+    }
+    return teams;
+}
+
 class Pipeline {
 public:
-    // `team`: with more than one device, every frame is split by tiles over these devices (and `gpus` is the team's
-    // first device alone); empty: every render thread renders whole frames on its own device
-    Pipeline(std::vector<std::string> files, int thread_count, int threading_type, std::vector<int> gpus, std::vector<int> team = {})
-        : thread_count_(thread_count), threading_type_(threading_type), gpus_(std::move(gpus)), team_(std::move(team)) {
+    // `gpus`: every device that renders (a device named twice gets two ranks: the many-GPU paths rehearsed on one GPU);
+    // `team_size`: devices that render a frame together.  The frames go to the teams in turn (the reference's dynamic
+    // hand-out of work, src/main.cpp:486-539, with a team in the place of a thread); when fewer frames are left than there
+    // are teams, all devices are regrouped into as many teams as frames are left (`tail_tiles`), so that a lone last
+    // frame, or a single file, is split by tiles over every GPU instead of leaving all but one idle.
+    Pipeline(std::vector<std::string> files, int thread_count, int threading_type, std::vector<int> gpus, size_t team_size, bool tail_tiles)
+        : thread_count_(thread_count), threading_type_(threading_type), gpus_(std::move(gpus)) {
         jobs_.resize(files.size());
         for (size_t i = 0; i < files.size(); ++i) jobs_[i].path = files[i];
+        teams_ = make_teams(gpus_, std::max<size_t>(1, team_size));
+        const size_t left_over = jobs_.size() % teams_.size();
+        bulk_frames_ = jobs_.size();
+        if (tail_tiles && left_over && gpus_.size() > left_over && spread_teams(gpus_, left_over)[0].devices.size() > teams_[0].devices.size()) {
+            bulk_frames_ = jobs_.size() - left_over;
+            tail_teams_ = spread_teams(gpus_, left_over);
+        }
     }
     ~Pipeline() {
-        for (rt_comm *c : comms_) rt_comm_destroy(c);
+        for (auto *teams : {&teams_, &tail_teams_})
+            for (Team &t : *teams)
+                for (rt_comm *c : t.comms) rt_comm_destroy(c);
     }
 
-    // false (with a message) when the team's communicators cannot be made
-    bool prepare() {
-        if (team_.size() < 2) return true;
-        comms_.assign(team_.size(), nullptr);
-        std::vector<int32_t> devices(team_.begin(), team_.end());
-        if (rt_comm_init_all((int32_t)devices.size(), devices.data(), comms_.data()) != 0) {
-            log_printf("Error: cannot set up %zu GPUs for tile-sharded frames: %s\n", team_.size(), rt_last_error());
-            comms_.clear();
-            return false;
+    // false (with a message) when a team's communicators cannot be made
+    static bool connect(std::vector<Team> &teams) {
+        for (Team &t : teams) {
+            if (t.devices.size() < 2 || !t.comms.empty()) continue;
+            t.comms.assign(t.devices.size(), nullptr);
+            std::vector<int32_t> devices(t.devices.begin(), t.devices.end());
+            if (rt_comm_init_all((int32_t)devices.size(), devices.data(), t.comms.data()) != 0) {
+                log_printf("Error: cannot set up %zu GPUs for tile-sharded frames: %s\n", t.devices.size(), rt_last_error());
+                t.comms.clear();
+                return false;
+            }
         }
         return true;
     }
+    bool prepare() { return bulk_frames_ == 0 || connect(teams_); }
 
     void run() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         // per render thread (one per GPU) up to four loaders and four writers: a 1080p frame of a light scene takes 4 ms to
         // render, 4-10 ms to parse and 16 ms to encode as PNG, so eight GPUs need eight times the helpers of one
-        const unsigned per_gpu = 4u * (unsigned)std::max<size_t>(1, gpus_.size());
+        const unsigned per_gpu = 4u * (unsigned)std::max<size_t>(1, teams_.size());
         const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), std::max(1u, std::min(per_gpu, hw / 4)));
         const unsigned n_write = std::max(1u, std::min(per_gpu, hw / 4));
         std::vector<std::thread> loaders, renderers, writers;
         for (unsigned i = 0; i < n_load; ++i) loaders.emplace_back([this] { load_loop(); });
         for (unsigned i = 0; i < n_write; ++i) writers.emplace_back([this] { write_loop(); });
-        for (int g : gpus_) renderers.emplace_back([this, g] { render_loop(g); });
-        for (auto &t : loaders) t.join();
+        // the teams beside each other while there is a frame for each, then everybody on what is left
+        render_limit_ = bulk_frames_;
+        if (bulk_frames_)
+            for (Team &team : teams_) renderers.emplace_back([this, &team] { render_loop(team); });
         for (auto &t : renderers) t.join();
+        renderers.clear();
+        if (!tail_teams_.empty()) {
+            if (!connect(tail_teams_)) {   // (said above) the frames that are left go to the teams as they were
+                if (!connect(teams_)) fail(flushed_, 1);
+                tail_teams_.clear();
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                render_limit_ = jobs_.size();
+            }
+            for (Team &team : tail_teams_.empty() ? teams_ : tail_teams_) renderers.emplace_back([this, &team] { render_loop(team); });
+            for (auto &t : renderers) t.join();
+        }
+        for (auto &t : loaders) t.join();
         {
             std::lock_guard<std::mutex> lk(m_);
             writers_may_stop_ = true;
@@ -199,7 +261,7 @@ private:
                 std::unique_lock<std::mutex> lk(m_);
                 i = next_load_++;
                 if (i >= jobs_.size()) return;
-                const size_t ahead = 2 * gpus_.size() + 2;
+                const size_t ahead = 2 * teams_.size() + 2;
                 cv_.wait(lk, [&] { return i < flushed_ + ahead; });
             }
             FileJob &job = jobs_[i];
@@ -230,15 +292,15 @@ private:
         _exit(code & 0xff);
     }
 
-    // ---- stage 2: one thread per GPU, scenes in file order ----------------------------------------------------
-    void render_loop(int gpu_index) {
+    // ---- stage 2: one thread per team of GPUs, scenes in file order ---------------------------------------------
+    void render_loop(Team &team) {
         for (;;) {
             size_t i;
             const auto t_wait = std::chrono::high_resolution_clock::now();
             {
                 std::unique_lock<std::mutex> lk(m_);
+                if (next_render_ >= render_limit_) return;
                 i = next_render_++;
-                if (i >= jobs_.size()) return;
                 cv_.wait(lk, [&] { return jobs_[i].loaded; });
             }
             FileJob &job = jobs_[i];
@@ -252,7 +314,7 @@ private:
             for (auto &w : job.scene.warnings) job_printf(job, "%s\n", w.c_str());
             // the reference makes this check per camera, before it spawns its threads (src/main.cpp:542-545)
             if (!job.scene.cameras.empty() && (thread_count_ > 4096 || thread_count_ < 1)) fail(i, -2);
-            render_scene(i, job, gpu_index);
+            render_scene(i, job, team);
             const auto t_tail = std::chrono::high_resolution_clock::now();
             job.scene = rth::HostScene();   // release the host arrays
             const double free_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_tail).count();
@@ -273,7 +335,10 @@ private:
         }
     }
 
-    void render_scene(size_t index, FileJob &job, int gpu_index) {
+    void render_scene(size_t index, FileJob &job, Team &crew) {
+        const int gpu_index = crew.devices[0];
+        const std::vector<int> &team_ = crew.devices;
+        const std::vector<rt_comm *> &comms_ = crew.comms;
         static const bool timing = getenv("RT_CLI_TIMING") != nullptr;   // diagnostic: stage times per file
         auto t_begin = std::chrono::high_resolution_clock::now();
         auto since = [&](std::chrono::high_resolution_clock::time_point t) {
@@ -288,13 +353,14 @@ private:
         // A team of GPUs: the other ranks run beside this thread, each with its own replica of the scene, and meet it in
         // rt_render_gather camera by camera.  They start rendering only when every replica exists.
         const size_t n_ranks = comms_.empty() ? 1 : comms_.size();
-        struct Team {
+        struct Sync {
             std::mutex m;
             std::condition_variable cv;
             size_t created = 0, failed = 0;
             std::vector<std::vector<rt_stats>> stats;   // [camera][rank], filled as the ranks finish a camera
             std::vector<size_t> reported;               // [camera]: ranks that have
             std::string error;
+            bool broken = false;                        // a rank has left its camera loop with an error
         } team;
         team.stats.assign(job.scene.cameras.size(), std::vector<rt_stats>(n_ranks));
         team.reported.assign(job.scene.cameras.size(), 0);
@@ -316,13 +382,18 @@ private:
                 }
                 for (size_t k = 0; ok && k < job.scene.cameras.size(); ++k) {
                     rt_stats st{};
-                    if (rt_render_gather(mine, comms_[r], &job.scene.cameras[k].desc, nullptr, &st) != 0) {
-                        fprintf(stderr, "rt_render_gather failed on GPU %d: %s\n", team_[r], rt_last_error());
-                        _exit(255);   // the other ranks wait for this one's tiles: the reference's way out of a failed render
-                    }
+                    // (a frame fails for every rank of the team, each with an error of its own: this rank's, or "a peer rank
+                    // failed"; all of them leave the camera loop here and the leader reports)
+                    const int rc = rt_render_gather(mine, comms_[r], &job.scene.cameras[k].desc, nullptr, &st);
                     std::lock_guard<std::mutex> lk(team.m);
-                    team.stats[k][r] = st;
-                    ++team.reported[k];
+                    if (rc != 0) {
+                        if (rc != 12) team.error = "GPU " + std::to_string(team_[r]) + ": " + rt_last_error();
+                        team.broken = true;
+                        ok = false;
+                    } else {
+                        team.stats[k][r] = st;
+                        ++team.reported[k];
+                    }
                     team.cv.notify_all();
                 }
                 if (mine) rt_scene_destroy(mine);
@@ -382,12 +453,20 @@ private:
                     fail(index, -1);
                 }
             } else {
-                if (rt_render_gather(gpu, comms_[0], &cam.desc, frame, &stats) != 0) {
-                    fprintf(stderr, "rt_render_gather failed: %s\n", rt_last_error());
-                    _exit(255);
+                if (const int rc = rt_render_gather(gpu, comms_[0], &cam.desc, frame, &stats)) {
+                    const std::string own = rt_last_error();
+                    for (auto &t : helpers) t.join();   // every rank has left the frame with an error
+                    job_printf(job, "rt_render_gather failed: %s\n", rc == 12 && !team.error.empty() ? team.error.c_str() : own.c_str());
+                    fail(index, -1);
                 }
                 std::unique_lock<std::mutex> lk(team.m);   // the frame is complete; the other ranks' ray counts follow
-                team.cv.wait(lk, [&] { return team.reported[camera_index] == n_ranks - 1; });
+                team.cv.wait(lk, [&] { return team.reported[camera_index] == n_ranks - 1 || team.broken; });
+                if (team.broken) {   // (an error behind the agreed status: the exchange itself)
+                    lk.unlock();
+                    for (auto &t : helpers) t.join();
+                    job_printf(job, "rt_render_gather failed: %s\n", team.error.c_str());
+                    fail(index, -1);
+                }
                 for (size_t r = 1; r < n_ranks; ++r) {
                     stats.primary_rays += team.stats[camera_index][r].primary_rays;
                     stats.shadow_rays += team.stats[camera_index][r].shadow_rays;
@@ -492,8 +571,10 @@ private:
     }
 
     int thread_count_, threading_type_;
-    std::vector<int> gpus_, team_;
-    std::vector<rt_comm *> comms_;   // one per rank of the team
+    std::vector<int> gpus_;
+    std::vector<Team> teams_, tail_teams_;   // who renders the frames in turn, and who renders the frames left over
+    size_t bulk_frames_ = 0;                 // frames handed to teams_; the rest goes to tail_teams_
+    size_t render_limit_ = 0;                // frames that may be taken in the current phase
     std::vector<FileJob> jobs_;
     std::vector<WriteTask> write_queue_;
     std::mutex m_;
@@ -553,32 +634,35 @@ int main(int argc, char **argv) {
         log_printf("Error: %s is neither a .json file nor a directory.\n", input.c_str());
         return 1;
     }
-    if (gpus.size() > files.size()) gpus.resize(std::max<size_t>(1, files.size()));
-    // RT_GPUS=<n>: GPUs 0 .. n-1 render every frame together, split by 32x32 tiles (a single heavy frame is the case for
-    // it; a directory of light frames is served better by the default, one frame per GPU).  RT_GPUS_DEVICES="0,0,0" names
-    // the team's devices instead (a repeated device rehearses the path on one GPU).
-    std::vector<int> team;
+    // RT_GPUS=<k>: teams of k GPUs render a frame together, split by 32x32 tiles, the teams beside each other (k = all the
+    // GPUs: every frame on the whole node, the case of a single heavy frame; a directory of light frames is served better
+    // by the default, one frame per GPU).  RT_GPUS_DEVICES="0,0,0,0" names the devices instead of RT_GPU (a repeated device
+    // rehearses the paths on one GPU); given alone it makes them one team.  Frames left over when fewer remain than there
+    // are teams go to all GPUs regrouped (RT_TAIL_TILES=0: they go to the teams as they are, the others idle).
+    size_t team_size = 1;
     if (const char *names = getenv("RT_GPUS_DEVICES")) {
+        gpus.clear();
         for (const char *p = names; *p;) {
-            team.push_back(atoi(p));
+            gpus.push_back(atoi(p));
             const char *comma = strchr(p, ',');
             if (!comma) break;
             p = comma + 1;
         }
-    } else if (const char *n = getenv("RT_GPUS")) {
-        int visible = 0;
-        if (hipGetDeviceCount(&visible) != hipSuccess) visible = 0;
+        if (gpus.empty()) gpus.push_back(0);
+        team_size = gpus.size();
+    }
+    if (const char *n = getenv("RT_GPUS")) {
         const int want = atoi(n);
-        if (want < 1 || want > visible) {
-            log_printf("Error: RT_GPUS=%s but %d GPU(s) are visible\n", n, visible);
+        if (want < 1 || (size_t)want > gpus.size()) {
+            log_printf("Error: RT_GPUS=%s but %zu GPU(s) are there to render\n", n, gpus.size());
             return 1;
         }
-        for (int g = 0; g < want; ++g) team.push_back(g);
+        team_size = (size_t)want;
     }
-    if (team.size() > 1) gpus.assign(1, team[0]);
+    const char *tail = getenv("RT_TAIL_TILES");
     const auto t_run = std::chrono::high_resolution_clock::now();
     {
-        Pipeline pipeline(files, thread_count, tt, gpus, team);
+        Pipeline pipeline(files, thread_count, tt, gpus, team_size, !(tail && atoi(tail) == 0));
         if (!pipeline.prepare()) return 1;
         pipeline.run();
     }

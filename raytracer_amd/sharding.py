@@ -73,16 +73,21 @@ def unpack_tiles(gathered, resx, resy, world):
 
 def exchange_unique_id(rank, world):
     """The RCCL id of a communicator over the ranks of the current torch.distributed group: made by rank 0 inside the
-    library, handed to the other ranks through torch.distributed (whatever backend it runs on)."""
+    library, handed to the other ranks through torch.distributed (whatever backend it runs on).  When rank 0 cannot make
+    the id (no RCCL to load) it says so IN the broadcast, so that every rank takes part in it and every rank raises the
+    same error afterwards: no rank is left waiting in a collective the others never enter."""
     buf = (C.c_ubyte * COMM_ID_BYTES)()
+    error = None
     if rank == 0:
         g = gpu_lib()
         if g.rt_comm_unique_id(buf, COMM_ID_BYTES) != 0:
-            raise RuntimeError(g.rt_last_error().decode())
-    box = [bytes(buf)]
+            error = g.rt_last_error().decode() or "rt_comm_unique_id failed"
+    box = [{"error": error} if error else bytes(buf)]
     if world > 1:
         # (torch is imported only here: a process that has already brought up /opt/rocm's HIP runtime through the library
         # must not load the second ROCm stack that torch ships; launchers of several ranks import torch first)
         import torch.distributed as dist
         dist.broadcast_object_list(box, src=0)
+    if isinstance(box[0], dict):
+        raise RuntimeError("rank 0 could not make the communicator's id: " + box[0]["error"])
     return box[0]

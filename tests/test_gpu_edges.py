@@ -200,39 +200,60 @@ def test_command_line_end_to_end(tmp_path, scene_dir):
     assert np.array_equal(png_pixels(str(tmp_path / "outputs" / "envmap_aces.png")), R.gpu_tonemap(frame, 2, 0.5, 0.0, 1.0, 1.8)[::-1])
 
 
-@pytest.mark.parametrize("render_threads", ["", "0,0,0"])
-def test_command_line_directory_of_frames(tmp_path, render_threads):
+@pytest.mark.parametrize("env_extra,n", [({}, 12), ({"RT_GPU": "0,0,0"}, 12), ({"RT_GPU": "0,0,0"}, 13),
+                                         ({"RT_GPUS_DEVICES": "0,0,0,0", "RT_GPUS": "2"}, 13),
+                                         ({"RT_GPUS_DEVICES": "0,0,0,0", "RT_GPUS": "2", "RT_TAIL_TILES": "0"}, 13),
+                                         ({"RT_GPU": "0,0,0,0,0,0,0,0"}, 3)])
+def test_command_line_directory_of_frames(tmp_path, env_extra, n):
     """A directory of scene files (an animation: one JSON per frame) goes through the loader / render / writer
     pipeline; every frame's image is written and equals a render through the ABI, and each file's log block stays
-    in one piece.  With RT_GPU=0,0,0 three render threads take the frames in turn, as on a node with three GPUs (here all
-    on device 0): same images, same log order."""
+    in one piece, the blocks in file order.  Rehearsals of a node with several GPUs on this box's one (a device named
+    several times):
+      RT_GPU=0,0,0                      three render threads take the frames in turn; a thirteenth frame is left over
+                                        and rendered by all three as a team (split by tiles, gathered)
+      RT_GPUS_DEVICES=0,0,0,0 RT_GPUS=2 two teams of two beside each other: frame-and-tile parallel; the frame left over
+                                        goes to one team of four (RT_TAIL_TILES=0: to a team of two, the other idles)
+      eight devices, three frames       fewer frames than GPUs: three teams of 3 + 3 + 2, every frame split by tiles"""
     import subprocess
     from test_host import png_pixels
     frames = tmp_path / "frames"
     frames.mkdir()
-    n = 12
     for k in range(n):
         def edit(s, k=k):
             cam = s["Cameras"]["Camera"]
             cam["Position"] = f"{0.05 * k} 0 0"
             cam["ImageName"] = f"anim_{k:04d}.png"
         patched(os.path.join(ROOT, "scenes", "simple.json"), str(frames / f"anim_{k:04d}.json"), edit)
-    env = dict(os.environ)
-    if render_threads:
-        env["RT_GPU"] = render_threads
+    env = dict(os.environ, **env_extra)
     r = subprocess.run([os.path.join(ROOT, "raytracer"), str(frames)], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert sum("rendering done:" in l for l in lines) == n
     starts = [i for i, l in enumerate(lines) if l.startswith("JSON parsing started")]
     assert len(starts) == n
+    done = []
     for a, b in zip(starts, starts[1:] + [len(lines)]):            # one "started" and one "done" per block
         block = lines[a:b]
         assert sum(l.endswith(".png started") for l in block) == 1 and sum("rendering done:" in l for l in block) == 1
-    for k in (0, n // 2, n - 1) if not render_threads else range(n):
+        done += [l.split()[0] for l in block if "rendering done:" in l]
+    assert sorted(done) == [f"anim_{k:04d}.png" for k in range(n)]
+    for k in (0, n // 2, n - 1) if not env_extra else range(n):
         sc = R.Scene(str(frames / f"anim_{k:04d}.json"))
         img, _ = R.Renderer(sc).render(sc.camera(0))
         assert np.array_equal(png_pixels(str(tmp_path / "outputs" / f"anim_{k:04d}.png")), R.gpu_quantize_ldr(img)[::-1])
+
+
+def test_command_line_team_reports_a_failed_frame_and_exits(tmp_path):
+    """A frame that a rank of the team cannot render (a camera without samples) ends the run with the reference's exit
+    behaviour -- message, non-zero status -- instead of leaving the other ranks waiting for its tiles."""
+    import subprocess
+
+    def edit(s):
+        s["Cameras"]["Camera"]["NumSamples"] = "0"
+    path = patched(os.path.join(ROOT, "scenes", "simple.json"), str(tmp_path / "bad.json"), edit)
+    r = subprocess.run([os.path.join(ROOT, "raytracer"), path], cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, RT_GPUS_DEVICES="0,0,0"))
+    assert r.returncode != 0 and "rt_render_gather failed" in r.stdout, r.stdout + r.stderr
 
 
 def test_repeated_frame_is_replayed_from_a_graph_with_the_same_result(tmp_path):

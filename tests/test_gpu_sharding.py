@@ -124,6 +124,85 @@ def test_single_rank_communicator_over_rccl(scene_dir):
     plain.close()
 
 
+def run_rccl_ranks(scene, world, failing, repo_root):
+    import json
+    import os
+    import subprocess
+    import sys
+    lib = os.path.join(repo_root, "tests", "tools", "libfake_rccl.so")
+    assert os.path.exists(lib), "tests/tools/libfake_rccl.so missing: run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "tests", "tools", "rccl_ranks.py"), scene, str(world), str(failing)],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, RT_RCCL_LIB=lib))
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rccl_branch_with_several_ranks(world, scene_dir, repo_root):
+    """The exchange as it runs with one process per GPU -- communicators from rt_comm_init_rank, the status all-reduce,
+    one ncclSend per rank and the root's grouped ncclRecv at their offsets -- with 2, 3 and 8 ranks on this box's one GPU:
+    a stand-in for librccl.so (tests/tools/fake_rccl.cpp, named through RT_RCCL_LIB, in a child process so that this
+    process keeps the real library) moves the data between threads.  Three frames through the same communicators, each
+    byte for byte rt_render's."""
+    scene = scenegen.write_mesh_scene(scene_dir, n=188, width=470, height=265)
+    res = run_rccl_ranks(scene, world, -1, repo_root)
+    assert not res["stuck"] and res["frame_equal"] == [True] * 3 and res["rays_equal"] == [True] * 3
+    assert all(e is None for per in res["errors"] for e in per)
+
+
+@pytest.mark.parametrize("world,failing", [(3, 2), (3, 0), (8, 5)])
+def test_failed_rank_fails_the_frame_and_strands_nobody(world, failing, scene_dir, repo_root):
+    """One rank's render fails in the second of three frames (a camera the renderer refuses): that rank returns its own
+    error, every other rank returns "a peer rank failed" instead of waiting in the exchange, and the third frame goes
+    through the same communicators as if nothing had happened."""
+    scene = scenegen.write_mesh_scene(scene_dir, n=188, width=470, height=265)
+    res = run_rccl_ranks(scene, world, failing, repo_root)
+    assert not res["stuck"]
+    assert res["frame_equal"] == [True, False, True] and res["rays_equal"][0] and res["rays_equal"][2]
+    bad = res["errors"][1]
+    assert all(e is not None for e in bad), bad
+    assert "sample count" in bad[failing]
+    assert all("peer rank failed" in e for r, e in enumerate(bad) if r != failing), bad
+    assert all(e is None for e in res["errors"][0] + res["errors"][2])
+
+
+@pytest.mark.parametrize("failing", [0, 1])
+def test_failed_rank_on_the_shared_device_transport(failing, scene_dir):
+    """The same with ranks that share a device (rt_comm_init_all, device-to-device copies): every rank reaches the meeting
+    point whatever went wrong on it."""
+    import threading
+    sc = R.Scene(scenegen.write_mesh_scene(scene_dir, n=188, width=470, height=265))
+    cam = sc.camera(0)
+    full, _ = R.Renderer(sc).render(cam)
+    world = 3
+    comms = R.Comm.init_all([0] * world)
+    rens = [R.Renderer(sc) for _ in range(world)]
+    errors = [[None] * world for _ in range(3)]
+    out = [None] * 3
+
+    def work(rank):
+        for f in range(3):
+            c = sc.camera(0, num_samples=0) if (f == 1 and rank == failing) else cam
+            try:
+                img, _ = rens[rank].render_gather(comms[rank], c)
+                if rank == 0:
+                    out[f] = img
+            except R.RaytracerError as e:
+                errors[f][rank] = str(e)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck at the meeting point"
+    assert all(e is None for e in errors[0] + errors[2]) and out[0].tobytes() == full.tobytes() and out[2].tobytes() == full.tobytes()
+    assert "sample count" in errors[1][failing]
+    assert all("peer rank failed" in e for r, e in enumerate(errors[1]) if r != failing), errors[1]
+    for c in comms:
+        c.close()
+
+
 def test_command_line_team_of_ranks(tmp_path, scene_dir, repo_root):
     """./raytracer with a team of three ranks (all on GPU 0: RT_GPUS_DEVICES) splits each camera's frame by tiles and
     gathers it; the PNG equals the one a single GPU writes."""

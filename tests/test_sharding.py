@@ -109,6 +109,50 @@ def test_two_rank_gather_is_byte_identical(tmp_path):
     assert out.tobytes() == full.tobytes()
 
 
+class _NoRccl:
+    """Stands in for the GPU library on rank 0: the id cannot be made."""
+
+    def rt_comm_unique_id(self, buf, n):
+        return 11
+
+    def rt_last_error(self):
+        return b"rt_comm_unique_id: librccl.so could not be loaded"
+
+
+def _id_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 0:
+        sharding.gpu_lib = lambda: _NoRccl()
+    try:
+        sharding.exchange_unique_id(rank, world)
+        said = "no error"
+    except RuntimeError as e:
+        said = str(e)
+    # what bench.py does next: every rank enters the same collective
+    ok = torch.tensor([0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(said)
+    dist.destroy_process_group()
+
+
+def test_failed_id_on_rank_zero_reaches_every_rank(tmp_path):
+    """Rank 0 cannot make the communicator's id: the failure travels in the broadcast, every rank raises it and all of
+    them meet again in the next collective (two gloo processes; it used to leave rank 1 in the broadcast for ever)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.spawn(_id_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False)
+    deadline = 120
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=1):
+        assert time.time() - t0 < deadline, "a rank hangs in the id exchange"
+    for r in range(2):
+        assert "librccl.so could not be loaded" in open(tmp_path / f"rank{r}.txt").read()
+
+
 def test_queue_shards_get_an_even_share_and_the_planner_knows_the_fullest():
     """Inside a device the camera samples of a batch are dealt to 64 queue shards (workgroup q of sample s -> shard
     (q + 37 s) mod 64): every quarter tile visits every shard within 64 samples, a shard's share of a batch stays within one
