@@ -9,7 +9,7 @@ HOST_SRCS = $(addprefix raytracer_amd/csrc/host/,ingest.cpp ply.cpp bvh_build.cp
 HOST_HDRS = $(wildcard raytracer_amd/csrc/host/*.h) include/gpu_render.h include/rt_host.h
 HIPFLAGS = --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-vector-combine -fPIC -std=c++17 -Iinclude -Iraytracer_amd/csrc/gpu
 
-all: raytracer_amd/librt_gpu.so raytracer_amd/librt_host.so raytracer oracle tests/tools/libfake_rccl.so
+all: raytracer_amd/librt_gpu.so raytracer_amd/librt_host.so raytracer oracle tests/tools/libfake_rccl.so tools/calibrate_fetch
 
 # two translation units: the render path, and the device BVH builder (it pulls in the radix sort of hipCUB, slow to compile)
 GPU_HDRS = $(wildcard raytracer_amd/csrc/gpu/*.h) include/gpu_render.h
@@ -28,6 +28,10 @@ raytracer_amd/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 
 raytracer: raytracer_amd/csrc/host/main.cpp raytracer_amd/librt_host.so raytracer_amd/librt_gpu.so
 	$(CXX) -std=c++17 -O2 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Iraytracer_amd/csrc/host $< -L/opt/rocm/lib -lamdhip64 -Lraytracer_amd -lrt_host -lrt_gpu -Wl,-rpath,'$$ORIGIN/raytracer_amd' -pthread -o $@
+
+# measurement: independent 64-byte gathers at known byte counts (bench.py times it for the gather ceiling of its roofline)
+tools/calibrate_fetch: tools/calibrate_fetch.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 $< -o $@
 
 # test infrastructure: a stand-in for librccl.so that carries the exchange between threads of one process (RT_RCCL_LIB)
 tests/tools/libfake_rccl.so: tests/tools/fake_rccl.cpp

@@ -10,11 +10,17 @@ Prints ONE JSON line on rank 0:
   value     = BVH traversals actually run (camera + bounce paths + shadow rays traced) of all ranks / max-over-ranks
               wall time, in Mrays/s.  value_reference_equivalent counts the rays the reference's algorithm casts for the
               same image (every light sample its own shadow ray) over the same time: the unit of cpu_baseline.
-  roofline  = memory-side traffic of the dominant kernel, measured in this run by two rocprofv3 counter passes over one
-              frame (FETCH_SIZE, WRITE_SIZE; child processes, before the timed frames), over its launch time from HIP
-              events in the timed frames, against the HBM peak; next to it the fixed per-ray byte model as a normaliser
+  roofline  = bytes the dominant kernel moves behind the L2 per launch, measured in this run by two rocprofv3 counter passes
+              over one frame (FETCH_SIZE, WRITE_SIZE; child processes, before the timed frames), over its launch time from
+              HIP events in the timed frames, against the HBM peak: `frac`.  FETCH_SIZE counts a gathered 64-byte record
+              as 64 bytes and a coalesced stream as half its bytes (calibrated on known byte counts), so the trace kernels'
+              reads enter as 1 x FETCH_SIZE and the streaming kernels' as 2 x.  `request_slot_frac` prices every read
+              request as the 128-byte line it occupies the memory side for; `frac_of_gather_ceiling` is the kernel's request
+              rate over that of independent 64-byte gathers measured in this run (tools/calibrate_fetch).  Next to them the
+              fixed per-ray byte model, a normaliser
   cpu_baseline = the reference renderer (oracle/_ref/raytracer, built from the reference sources)
-              or, when absent, the in-repo CPU restatement, timed on this host on a bounded sample
+              or, when absent, the in-repo CPU restatement, timed on this host on a bounded sample with every CPU this
+              process may use
 """
 import argparse
 import ctypes as C
@@ -55,9 +61,43 @@ def make_scene(scenegen, out_dir, w, name, cpu=False):
     return scenegen.write_mesh_scene(out_dir, name=name, n=w["n"], width=dims["width"], height=dims["height"])
 
 
+def host_threads():
+    """Threads the CPU leg runs: every CPU this process may use -- its affinity mask, cut to the container's CPU quota and
+    to the share the box announces through OMP_NUM_THREADS where those are set (a GPU box shows the whole machine's CPUs
+    to a job that owns a fraction of them).  Returns (threads, description of how the number came about)."""
+    host = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = host
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(period)))
+    except (OSError, ValueError):
+        pass
+    share = None
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", ""))
+    except ValueError:
+        pass
+    threads = affinity
+    if quota:
+        threads = min(threads, quota)
+    if share and share > 0:
+        threads = min(threads, share)
+    return max(1, threads), {"host_cpus": host, "affinity": affinity, "cgroup_quota": quota, "announced_share": share}
+
+
+REFERENCE_BUILD = ("g++ -std=c++20 -O3 -march=x86-64-v3 -ffast-math -ftree-vectorize -msse4.1 -flto=8 -DNDEBUG: the reference Makefile's "
+                   "flags with its -march=native replaced by x86-64-v3 (AVX2 + FMA), because the binary is built in another container "
+                   "than it runs in")
+
+
 def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
     """Times the CPU renderer on a bounded sample of the workload; returns the JSON object."""
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads, how = host_threads()
     path = make_scene(scenegen, scene_dir, w, "cpu_sample", cpu=True)
     dims = dict(w)
     dims.update(w["cpu"])
@@ -79,7 +119,8 @@ def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
                 if m and int(m.group(1)) > 0:
                     ms = float(m.group(1))
                     return {"value": rays / ms / 1e3, "unit": "Mrays/s", "cores": threads, "kind": "reference",
-                            "sample": sample, "ms": ms}
+                            "sample": sample, "ms": ms, "threads": how, "reference_build": REFERENCE_BUILD,
+                            "scheduler": "row_dynamic (threading_type 0)"}
             except (subprocess.SubprocessError, OSError):
                 pass
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -88,7 +129,8 @@ def cpu_baseline(R, scenegen, w, scene_dir, rays_per_unit_hint):
     t0 = time.perf_counter()
     _, so = orc.render(cam, threads=threads)
     ms = (time.perf_counter() - t0) * 1e3
-    return {"value": so.total_rays / ms / 1e3, "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample, "ms": ms}
+    return {"value": so.total_rays / ms / 1e3, "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": sample, "ms": ms,
+            "threads": how}
 
 
 def kernel_bytes(st, timed):
@@ -186,14 +228,27 @@ def measure_traffic(workload):
     return out
 
 
+def fetch_factor(kernel_class):
+    """What FETCH_SIZE has to be multiplied by to give bytes, per access class (tools/calibrate_fetch.sh): the trace
+    kernels gather 64-byte records, which the counter reports as they are; every other kernel streams its queue
+    records, which it reports at half (the microarchitecture guide's gfx950 correction)."""
+    return 1.0 if kernel_class.startswith("trace") else 2.0
+
+
 def gather_ceiling():
-    """Measured rate of independent 64-byte record gathers from tables of the benchmark tree's size on this GPU model
-    (tools/calibrate_fetch.hip; the committed run): requests per second, or None."""
+    """Rate of independent 64-byte record gathers from a 128 MiB table (the size class of the benchmark's tree: beyond the
+    L2s, inside the Infinity Cache), measured now, on this GPU, by tools/calibrate_fetch (a child process, before this
+    process holds device memory): requests per second, or None when the binary is not there or fails."""
+    exe = os.path.join(ROOT, "tools", "calibrate_fetch")
+    if not os.path.exists(exe):
+        return None
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r2_fetch_calibration.json")))
-        rows = [doc[k]["gather64"] for k in ("64", "128")]
-        return min(r["GBps_unprofiled"] for r in rows) * 1e9 / 64.0
-    except (OSError, ValueError, KeyError):
+        out = subprocess.run([exe, "128"], capture_output=True, text=True, timeout=120)
+        if out.returncode != 0:
+            return None
+        rates = [float(f[8]) for f in (line.split() for line in out.stdout.splitlines()) if len(f) >= 9 and f[0] == "gather64" and f[7] == "GBps"]
+        return max(rates) * 1e9 / 64.0 if rates else None
+    except (subprocess.SubprocessError, OSError, ValueError):
         return None
 
 
@@ -240,8 +295,10 @@ def main():
     path = make_scene(scenegen, scene_dir, w, args.workload)
     # counter passes first, while this process holds no device memory (the children render the same frame)
     traffic_by_kernel = None
+    ceiling = None
     if world == 1 and not args.timed_frames_only and not args.no_pmc:
         traffic_by_kernel = measure_traffic(args.workload)
+        ceiling = gather_ceiling()
     sc = R.Scene(path)
     cam = sc.camera(0)
     ren = R.Renderer(sc)   # scene resident in HBM from here on (a full replica on every rank)
@@ -365,20 +422,26 @@ def main():
                                "note": "normaliser only: bytes of the reference's node-by-node walk, served mostly from LDS/L1/L2"}}
         if t:
             sec = ms_per_launch * 1e-3
-            line_slot_bytes = 2.0 * t["fetch_size_bytes"] + t["write_size_bytes"]
+            factor = fetch_factor(name)
+            true_bytes = factor * t["fetch_size_bytes"] + t["write_size_bytes"]
+            slot_bytes = 2.0 * t["fetch_size_bytes"] + t["write_size_bytes"]
             roof.update({
-                "traffic": line_slot_bytes, "achieved": line_slot_bytes / sec / 1e9, "frac": line_slot_bytes / sec / 1e9 / HBM_PEAK_GBS,
-                "traffic_definition": "memory-side bytes per launch measured in this run: 128 B per L2 read request (2 x FETCH_SIZE; a "
-                                      "request occupies the memory side like a whole line, tools/calibrate_fetch.sh) + WRITE_SIZE",
-                "requested_bytes": t["fetch_size_bytes"] + t["write_size_bytes"],
-                "requested_frac": (t["fetch_size_bytes"] + t["write_size_bytes"]) / sec / 1e9 / HBM_PEAK_GBS,
+                "traffic": true_bytes, "achieved": true_bytes / sec / 1e9, "frac": true_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                "fetch_size_factor": factor,
+                "traffic_definition": "bytes moved behind the L2 per launch, measured in this run: FETCH_SIZE x the factor calibrated for the "
+                                      "kernel's access class (1 for the trace kernels' 64-byte record gathers, 2 for coalesced streams: "
+                                      "tools/calibrate_fetch.sh, profiles/r2_fetch_calibration.json) + WRITE_SIZE",
+                "request_slot_bytes": slot_bytes, "request_slot_frac": slot_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                "request_slot_definition": "128 B per L2 read request + WRITE_SIZE: a request occupies the memory side like a whole line "
+                                           "whatever it moves (60 G requests/s x 128 B = the 8 TB/s peak); how busy the request path is, not bytes",
                 "read_requests_per_launch": t["read_requests"], "read_requests_per_s": t["read_requests"] / sec})
-            ceil = gather_ceiling()
-            if ceil and name.startswith("trace"):
-                roof["gather_ceiling_requests_per_s"] = ceil
-                roof["frac_of_gather_ceiling"] = t["read_requests"] / sec / ceil
+            if ceiling and name.startswith("trace"):
+                roof["gather_ceiling_requests_per_s"] = ceiling
+                roof["gather_ceiling_definition"] = "independent 64-byte record gathers from a 128 MiB table, measured in this run (tools/calibrate_fetch)"
+                roof["frac_of_gather_ceiling"] = t["read_requests"] / sec / ceiling
         if traffic_by_kernel:
-            roof["traffic_per_frame_by_kernel"] = {k: (2.0 * v["fetch_size_bytes"] + v["write_size_bytes"]) * v["launches"] for k, v in traffic_by_kernel.items()}
+            roof["traffic_per_frame_by_kernel"] = {k: (fetch_factor(k) * v["fetch_size_bytes"] + v["write_size_bytes"]) * v["launches"]
+                                                   for k, v in traffic_by_kernel.items()}
         line = {
             "metric": "Mrays/s (primary+shadow+secondary), whole job", "value": traced / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

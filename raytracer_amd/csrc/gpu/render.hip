@@ -127,7 +127,7 @@ struct Wavefront {
 constexpr int N_SHARDS = 64;
 constexpr int COUNTER_STRIDE = 32;   // in 4-byte words
 enum { Q_PATH = 0, Q_VERTEX = 1, Q_SHADOW = 2 };
-__device__ __forceinline__ unsigned *counter_of(const Wavefront &W, int kind, int gen, int shard) {
+__host__ __device__ __forceinline__ unsigned *counter_of(const Wavefront &W, int kind, int gen, int shard) {
     return W.counters + ((size_t)(kind * W.generations + gen) * N_SHARDS + shard) * COUNTER_STRIDE;
 }
 
@@ -2360,13 +2360,22 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
     // ends with the camera rays (src/ray_trace.cpp:681-869 spawns rays for mirror, conductor and dielectric only), and the
     // later generations would be launches over empty queues: 30 of the 35 of a 1080p frame of the 70K-triangle scene
     const int n_gen = !pt && s->only_regular_materials ? 1 : (int)ceilf(s->dev.max_depth) + 1;
-    while ((int)s->shaded.size() < n_gen) {
-        hipEvent_t a, b;
-        HIP_OK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        s->shaded.push_back(a);
-        HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        s->lit.push_back(b);
-    }
+    // A depth limit far beyond what paths live (the reference takes any MaxRecursionDepth, src/parser.cpp:1253-1258) must
+    // not cost its launches: from generation GEN_CHECK on, every GEN_CHECK generations, the host waits for the shading
+    // that fed the next generation's queue and reads its 64 counters; an empty queue makes that generation the last (it runs,
+    // over nothing, so that the lighting of the one before is closed as after any last generation).  The two events of a
+    // generation are made when the loop reaches it.
+    constexpr int GEN_CHECK = 32;
+    auto generation_events = [&](int gen) -> int {
+        while ((int)s->shaded.size() <= gen) {
+            hipEvent_t a, b;
+            HIP_OK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            s->shaded.push_back(a);
+            HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            s->lit.push_back(b);
+        }
+        return 0;
+    };
     // The lighting chain of a generation can run on a second stream beside the closest-hit trace and shading of the next
     // one (RT_TWO_STREAMS=1).  It is off by default: once every kernel fills the chip by itself the overlap gains nothing
     // (4K / 64 spp frame 743 vs 740 ms, 1080p / 1 spp frame 1.27 vs 1.24 ms), and on one stream the per-kernel event times
@@ -2436,7 +2445,17 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 else
                     hipLaunchKernelGGL(light_gather_kernel<false>, dim3(grid), dim3(256), 0, on, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, 1, share_rays && s->pass_has_emitter[0] ? 1 : 0, s->stats);
             };
-            for (int gen = 0; gen < n_gen; ++gen) {
+            int gens = n_gen;   // generations this batch runs: n_gen, or fewer when its paths have all ended
+            for (int gen = 0; gen < gens; ++gen) {
+                if (int rc = generation_events(gen)) return rc;
+                if (gen >= GEN_CHECK && gen % GEN_CHECK == 0 && gen < gens - 1) {   // (never inside a graph capture: see `key` below)
+                    unsigned fill[N_SHARDS * COUNTER_STRIDE];
+                    HIP_OK(hipStreamSynchronize(s->stream));
+                    HIP_OK(hipMemcpy(fill, counter_of(W, Q_PATH, gen, 0), sizeof fill, hipMemcpyDeviceToHost));
+                    unsigned long long alive = 0;
+                    for (int sh = 0; sh < N_SHARDS; ++sh) alive += fill[sh * COUNTER_STRIDE];
+                    if (!alive) gens = gen + 1;
+                }
                 launch_trace(s, s->stream, false, grid, gen, pt ? 0 : 1);
                 if (pair_gather && gen >= 1) {   // the gather of the generation before, beside this generation's shading
                     HIP_OK(hipEventRecord(s->shaded[gen], s->stream));   // (here: "closest hits of `gen` found", and with them the shadow rays of gen - 1)
@@ -2462,7 +2481,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                         hipLaunchKernelGGL(setup_fn(0), dim3(grid), dim3(256), 0, s->stream, s->dev, W, gen, 0, s->light_of, s->k_total, (int)slots_per_vertex, slot_table, share_rays, s->stats);
                     }
                     launch_trace(s, s->stream, true, grid, gen, emitter_rays ? 1 : 0);
-                    if (gen == n_gen - 1) {
+                    if (gen == gens - 1) {
                         launch_gather(s->stream, gen);
                         HIP_OK(hipEventRecord(s->lit[gen], s->stream));
                     }
@@ -2493,7 +2512,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
                 }
                 HIP_OK(hipEventRecord(s->lit[gen], lighting));
             }
-            for (int gen = std::max(0, n_gen - 2); gen < n_gen; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
+            for (int gen = std::max(0, gens - 2); gen < gens; ++gen) HIP_OK(hipStreamWaitEvent(s->stream, s->lit[gen], 0));
             {
                 LaunchTimer timer(s, RT_KERNEL_RESOLVE, s->stream);
                 hipLaunchKernelGGL(resolve_kernel, dim3((b.n_pixels + 255) / 256), dim3(256), 0, s->stream, *cam, b, W, dev_out, packed ? 1 : 0);
@@ -2506,7 +2525,7 @@ static int render_tiles(rt_scene *s, const rt_camera_desc *cam, int rank, int wo
         // HIP graph and replayed from then on: its forty-odd short launches become one (RT_FRAME_GRAPH=0: never).
         static const bool graphs_allowed = !(getenv("RT_FRAME_GRAPH") && atoi(getenv("RT_FRAME_GRAPH")) == 0);
         unsigned long long key = 0;
-        if (graphs_allowed && !s->frame_graph_off && world == 1 && !s->profiling && !s->counters && !two_streams && !pair_gather && tile == 0 && tiles_now == n_owned &&
+        if (graphs_allowed && n_gen <= GEN_CHECK && !s->frame_graph_off && world == 1 && !s->profiling && !s->counters && !two_streams && !pair_gather && tile == 0 && tiles_now == n_owned &&
             !getenv("RT_PRINT_BATCHES")) {
             key = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t n) {

@@ -125,10 +125,12 @@ __global__ void __launch_bounds__(TM_THREADS) tm_quantize_kernel(const float *__
     }
 }
 
-bool tm_on_device(const void *p) {
+// `device_out`: the GPU that holds the memory (when it is device memory)
+bool tm_on_device(const void *p, int *device_out = nullptr) {
     hipPointerAttribute_t attr;
     const bool dev = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
+    if (dev && device_out) *device_out = attr.device;
     return dev;
 }
 
@@ -253,8 +255,15 @@ int rt_tonemap_noalloc(const float *hdr, int32_t width, int32_t height, const rt
         g_error = "rt_tonemap_noalloc: frame larger than RT_TONEMAP_NOALLOC_MAX_PIXELS (2^28 pixels: ranks and histogram counts in the scratch buffer are 32-bit)";
         return 5;
     }
-    if (!tm_on_device(hdr) || !tm_on_device(rgb8_out)) {
+    int current = -1, dev_in = -1, dev_out = -1;
+    HIP_OK(hipGetDevice(&current));
+    if (!tm_on_device(hdr, &dev_in) || !tm_on_device(rgb8_out, &dev_out)) {
         g_error = "rt_tonemap_noalloc: hdr and rgb8_out must be device memory (staging host buffers would need an allocation)";
+        return 1;
+    }
+    if (dev_in != current || dev_out != current) {   // the kernels run on the current device with that device's scratch array
+        g_error = "rt_tonemap_noalloc: hdr and rgb8_out must be memory of the current device (hdr is on GPU " + std::to_string(dev_in) + ", rgb8_out on GPU " +
+                  std::to_string(dev_out) + ", current is GPU " + std::to_string(current) + ")";
         return 1;
     }
     void *base = nullptr;

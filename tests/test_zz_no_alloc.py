@@ -100,3 +100,13 @@ def test_noalloc_tonemap_rejects_what_it_cannot_do(hip):
     assert g.rt_tonemap_noalloc(host.ctypes.data, 4, 4, C.byref(desc), out) == 1    # host memory
     assert b"device memory" in g.rt_last_error()
     assert g.rt_tonemap_noalloc(hdr, 4, 4, C.byref(desc), out) == 0
+    # memory of another GPU: the kernels would run on the current device with its own scratch array (a box with one GPU
+    # has nothing to try this on)
+    count = C.c_int(0)
+    assert hip.rt.hipGetDeviceCount(C.byref(count)) == 0
+    if count.value > 1:
+        assert hip.rt.hipSetDevice(1) == 0
+        far = hip.filled(4 * 4 * 3, 0)
+        assert hip.rt.hipSetDevice(0) == 0
+        assert g.rt_tonemap_noalloc(hdr, 4, 4, C.byref(desc), far) == 1
+        assert b"current device" in g.rt_last_error()
