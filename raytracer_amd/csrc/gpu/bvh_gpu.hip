@@ -2,16 +2,22 @@
 // bvh_prim_bounds given).
 //
 // The reference builds its tree on one host thread by recursive SAH splits (src/bvh.cpp:41-344); an animation rebuilds it
-// for every frame.  This builder trades tree quality for build time: primitives are ordered along a 63-bit Morton curve of
-// their box centres, the hierarchy comes from the common prefixes of neighbouring codes (one thread per interior node, no
-// dependencies between them), boxes are fitted bottom-up, and the result is written straight into the records the trace
-// kernel walks -- two child boxes per interior node, one leaf per primitive.  The tree differs from the reference's, so
-// rays meet primitives in another order: the closest hit is the same, and only hits at exactly equal distance may resolve
-// to another primitive (the reference keeps the first it finds, src/bvh.cpp:445).
+// for every frame.  Here the primitives are ordered along a 63-bit Morton curve of their box centres and the tree is grown
+// bottom-up by clustering along that order (parallel locally-ordered clustering): every cluster looks RADIUS places to
+// either side for the neighbour whose union with it has the least surface area, pairs that choose each other merge into a
+// node, and the survivors are compacted in order for the next round -- some forty rounds for a million primitives, each a
+// few short launches.  The surface area of the union is what the reference's split cost weighs (src/bvh.cpp:249-259), so the
+// clusters that end up together are the ones a SAH split would keep together.  While the tree grows every node learns the
+// cost of its subtree by the reference's rule (src/bvh.cpp:259-274: 0.125 + the children's costs weighted by their share of
+// the node's area, against one unit per primitive for a leaf of at most four), and a node that is cheaper as a leaf becomes
+// one: its primitives' entries are laid out next to each other and tested one after the other, like a leaf of the
+// reference's tree.  The result is written straight into the records the trace kernel walks -- two child boxes per interior
+// node, leaves of one to four primitives.  The tree differs from the reference's, so rays meet primitives in another order:
+// the closest hit is the same, and only hits at exactly equal distance may resolve to another primitive (the reference
+// keeps the first it finds, src/bvh.cpp:445).
 //
-// A node's children are ordered by the bit in which their codes first differ: the left child has 0 there, i.e. the lower
-// coordinate on that bit's axis, which is what the walk's "near child first by the sign of the direction on the split axis"
-// expects (src/bvh.cpp:459-474).
+// A node's children are ordered along the axis on which their centres lie furthest apart: the left child is the lower one,
+// which is what the walk's "near child first by the sign of the direction on the split axis" expects (src/bvh.cpp:459-474).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -79,104 +85,221 @@ __global__ void __launch_bounds__(256) morton_kernel(const float *__restrict__ b
     order[i] = (unsigned)i;
 }
 
-// length of the common prefix of the codes at sorted positions i and j; equal codes are told apart by their position
-__device__ __forceinline__ int prefix(const unsigned long long *__restrict__ keys, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    const unsigned long long a = keys[i], b = keys[j];
-    if (a != b) return __clzll((long long)(a ^ b));
-    return 64 + __clz(i ^ j);
+// ---- clustering along the Morton order -------------------------------------------------------------------------------
+// A cluster: a node reference (leaf ~j of sorted position j, or interior node id), its box, and what is known of its
+// subtree: {depth in interior nodes, primitives, cost (float bits), 1 when the subtree is one leaf}.
+__device__ __forceinline__ float half_area(const float *b) {
+    const float x = b[3] - b[0], y = b[4] - b[1], z = b[5] - b[2];
+    return x * y + x * z + y * z;
+}
+__device__ __forceinline__ float union_area(const float *a, const float *b) {
+    const float x = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), y = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), z = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return x * y + x * z + y * z;
 }
 
-// One thread per interior node (n - 1 of them): its range of sorted primitives, its split, its children.  child < 0:
-// leaf ~child.  `axis_bit` = 1 << axis of the code bit in which the two children first differ.
-__global__ void __launch_bounds__(256) hierarchy_kernel(const unsigned long long *__restrict__ keys, int n, int *__restrict__ left, int *__restrict__ right,
-                                                         int *__restrict__ parent_of_node, int *__restrict__ parent_of_leaf, int *__restrict__ axis_bit) {
+__global__ void __launch_bounds__(256) ploc_leaves_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int n, int *__restrict__ ref,
+                                                           float *__restrict__ box, int4 *__restrict__ info) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    ref[j] = ~j;
+    info[j] = make_int4(0, 1, __float_as_int(1.0f), 1);
+    const float *b = bounds + 6 * (size_t)order[j];
+    for (int a = 0; a < 6; ++a) box[6 * (size_t)j + a] = b[a];
+}
+
+// nearest[i]: the cluster within `radius` places of i whose union with i has the least area.  Ties go to the pair (2 m,
+// 2 m + 1) first, then to the lower (smaller index, larger index): a total order on pairs, so the best pair of a round
+// always choose each other and every round merges at least once -- and a pile of identical boxes pairs off in every round
+// (a balanced tree) instead of growing a chain from one end.
+__global__ void __launch_bounds__(256) ploc_nearest_kernel(const float *__restrict__ box, int nc, int radius, int *__restrict__ nearest) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n - 1) return;
-    const int d = prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    const int floor_prefix = prefix(keys, n, i, i - d);
-    int reach = 2;
-    while (prefix(keys, n, i, i + reach * d) > floor_prefix) reach <<= 1;
-    int len = 0;
-    for (int t = reach >> 1; t > 0; t >>= 1)
-        if (prefix(keys, n, i, i + (len + t) * d) > floor_prefix) len += t;
-    const int j = i + len * d;
-    const int node_prefix = prefix(keys, n, i, j);
-    int s = 0;
-    for (int t = (len + 1) >> 1;; t = (t + 1) >> 1) {
-        if (prefix(keys, n, i, i + (s + t) * d) > node_prefix) s += t;
-        if (t == 1) break;
-    }
-    const int split = i + s * d + min(d, 0);
-    const int lo = min(i, j), hi = max(i, j);
-    const int l = lo == split ? ~split : split, r = hi == split + 1 ? ~(split + 1) : split + 1;
-    left[i] = l, right[i] = r;
-    if (l < 0) parent_of_leaf[~l] = i; else parent_of_node[l] = i;
-    if (r < 0) parent_of_leaf[~r] = i; else parent_of_node[r] = i;
-    if (i == 0) parent_of_node[0] = -1;
-    // the first differing bit of the two halves: bit 63 - node_prefix of the code (x: bits 2 mod 3, y: 1, z: 0)
-    axis_bit[i] = node_prefix < 64 ? 1 << (2 - (63 - node_prefix) % 3) : 1;
-}
-
-// One thread per leaf: climbs while it is the second to arrive, fitting each node's box from its children's.
-__global__ void __launch_bounds__(256) fit_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int n, const int *__restrict__ left,
-                                                   const int *__restrict__ right, const int *__restrict__ parent_of_node, const int *__restrict__ parent_of_leaf,
-                                                   float *__restrict__ node_box, unsigned *__restrict__ arrived, int *__restrict__ deepest) {
-    const int leaf = blockIdx.x * 256 + threadIdx.x;
-    if (leaf >= n) return;
-    int node = parent_of_leaf[leaf], steps = 1;
-    for (int up = node; up >= 0 && parent_of_node[up] >= 0; up = parent_of_node[up]) ++steps;
-    atomicMax(deepest, steps);
-    while (node >= 0) {
-        __threadfence();
-        if (atomicAdd(&arrived[node], 1u) == 0u) return;   // the sibling's subtree is not finished: that thread goes on
-        __threadfence();
-        float box[6] = {3.4e38f, 3.4e38f, 3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
-        const int kids[2] = {left[node], right[node]};
-        for (int k = 0; k < 2; ++k) {
-            const volatile float *b = kids[k] < 0 ? bounds + 6 * (size_t)order[~kids[k]] : node_box + 6 * (size_t)kids[k];
-            for (int a = 0; a < 3; ++a) {
-                box[a] = fminf(box[a], b[a]);
-                box[3 + a] = fmaxf(box[3 + a], b[3 + a]);
-            }
+    if (i >= nc) return;
+    float mine[6];
+    for (int a = 0; a < 6; ++a) mine[a] = box[6 * (size_t)i + a];
+    float best = 3.4e38f;
+    int arg = -1;
+    const int lo = max(0, i - radius), hi = min(nc - 1, i + radius);
+    for (int k = lo; k <= hi; ++k) {
+        if (k == i) continue;
+        const float area = union_area(mine, box + 6 * (size_t)k);
+        bool better = arg < 0 || area < best;
+        if (!better && area == best) {
+            const bool buddy_k = (i ^ k) == 1, buddy_arg = (i ^ arg) == 1;
+            better = buddy_k != buddy_arg ? buddy_k : (min(i, k) < min(i, arg) || (min(i, k) == min(i, arg) && max(i, k) < max(i, arg)));
         }
-        for (int a = 0; a < 6; ++a) node_box[6 * (size_t)node + a] = box[a];
-        node = parent_of_node[node];
+        if (better) best = area, arg = k;
+    }
+    nearest[i] = arg;
+}
+
+// flags[i]: low word 1 when cluster i survives the round (alone, or as the lower partner of a merge), high word 1 when it
+// is the lower partner of a merge; an exclusive scan of the flags gives the survivor's new place and the new node's number
+__global__ void __launch_bounds__(256) ploc_flag_kernel(const int *__restrict__ nearest, int nc, unsigned long long *__restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc) return;
+    const int j = nearest[i];
+    const bool mutual = j >= 0 && nearest[j] == i;
+    flags[i] = (mutual && i > j ? 0ull : 1ull) | (mutual && i < j ? 1ull << 32 : 0ull);
+}
+
+struct TreeArrays {   // per interior node id (in the order the nodes are made: children before parents)
+    int *left, *right, *parent, *axis_bit;
+    int *live;        // interior nodes of the subtree that the walk can reach (0 for a subtree that became a leaf)
+    int4 *info;       // as a cluster's
+    float *box;
+    int *parent_of_leaf;   // per sorted position
+};
+
+__global__ void __launch_bounds__(256) ploc_merge_kernel(const int *__restrict__ nearest, const unsigned long long *__restrict__ flags,
+                                                          const unsigned long long *__restrict__ scanned, int nc, int first_node, const int *__restrict__ ref_in,
+                                                          const float *__restrict__ box_in, const int4 *__restrict__ info_in, int *__restrict__ ref_out,
+                                                          float *__restrict__ box_out, int4 *__restrict__ info_out, TreeArrays T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc) return;
+    const unsigned long long f = flags[i];
+    if (!(f & 1ull)) return;   // merged into its partner
+    const int place = (int)(scanned[i] & 0xffffffffull);
+    if (!(f >> 32)) {          // survives as it is
+        ref_out[place] = ref_in[i];
+        info_out[place] = info_in[i];
+        for (int a = 0; a < 6; ++a) box_out[6 * (size_t)place + a] = box_in[6 * (size_t)i + a];
+        return;
+    }
+    const int j = nearest[i];
+    const int id = first_node + (int)(scanned[i] >> 32);
+    const float *bi = box_in + 6 * (size_t)i, *bj = box_in + 6 * (size_t)j;
+    // the axis on which the two centres lie furthest apart; the lower one goes left
+    int axis = 0;
+    float far = -1.0f, diff = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float d = (bi[a] + bi[3 + a]) - (bj[a] + bj[3 + a]);
+        if (fabsf(d) > far) far = fabsf(d), axis = a, diff = d;
+    }
+    const bool i_first = diff <= 0.0f;
+    const int l = i_first ? ref_in[i] : ref_in[j], r = i_first ? ref_in[j] : ref_in[i];
+    T.left[id] = l, T.right[id] = r;
+    if (l < 0) T.parent_of_leaf[~l] = id; else T.parent[l] = id;
+    if (r < 0) T.parent_of_leaf[~r] = id; else T.parent[r] = id;
+    T.parent[id] = -1;   // (until a later round says otherwise)
+    T.axis_bit[id] = 1 << axis;
+    float u[6];
+    for (int a = 0; a < 3; ++a) u[a] = fminf(bi[a], bj[a]), u[3 + a] = fmaxf(bi[3 + a], bj[3 + a]);
+    for (int a = 0; a < 6; ++a) T.box[6 * (size_t)id + a] = u[a], box_out[6 * (size_t)place + a] = u[a];
+    // cost of the subtree by the reference's rule (src/bvh.cpp:259-274), and whether it is cheaper as one leaf
+    const int4 ii = info_in[i], ij = info_in[j];
+    const int count = ii.y + ij.y;
+    const float area = half_area(u);
+    float cost = 0.125f + (area > 0.0f ? (half_area(bi) * __int_as_float(ii.z) + half_area(bj) * __int_as_float(ij.z)) / area : (float)count);
+    const bool leaf = count <= 4 && ii.w && ij.w && (float)count <= cost;
+    if (leaf) cost = (float)count;
+    const int4 mine = make_int4(leaf ? 0 : 1 + max(ii.x, ij.x), count, __float_as_int(cost), leaf ? 1 : 0);
+    T.info[id] = mine;
+    T.live[id] = leaf ? 0 : 1 + (l < 0 ? 0 : T.live[l]) + (r < 0 ? 0 : T.live[r]);
+    ref_out[place] = id;
+    info_out[place] = mine;
+}
+
+// Where every primitive's entry goes: the tree's leaves from left to right, a leaf's primitives next to each other.  One
+// thread per sorted position climbs to the root, adding up the primitives of the subtrees to its left; the topmost
+// ancestor that is a leaf (if any) is the leaf it belongs to.  place[j] = its entry, leaf_of[j] = that ancestor or -1,
+// and for such an ancestor first_entry[] = the place of its first primitive (every one of its primitives writes the same value).
+__global__ void __launch_bounds__(256) ploc_places_kernel(int n, TreeArrays T, int *__restrict__ place, int *__restrict__ leaf_of, int *__restrict__ first_entry) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    int before = 0, child = ~j, leaf = -1, before_in_leaf = 0;
+    for (int node = T.parent_of_leaf[j]; node >= 0; node = T.parent[node]) {
+        if (T.right[node] == child) {
+            const int l = T.left[node];
+            before += l < 0 ? 1 : T.info[l].y;
+        }
+        if (T.info[node].w) leaf = node, before_in_leaf = before;
+        child = node;
+    }
+    place[j] = before;
+    leaf_of[j] = leaf;
+    if (leaf >= 0) first_entry[leaf] = before - before_in_leaf;
+}
+
+// Where a node's record goes.  The walk reads a child right after its parent, so the records stand in the order of the
+// reference's array (src/bvh.cpp:316-344: a node, its left subtree, its right subtree): a left child lies next to its
+// parent.  The top of the tree -- the nodes less than TOP_LEVELS steps below the root, which every ray visits and the trace
+// kernel keeps in LDS -- comes first, level by level (heap numbering: 2 h + 1, 2 h + 2).  One thread per node climbs to the
+// root to find both numbers.  Nodes inside a subtree that became a leaf get no record.
+constexpr int TOP_LEVELS = 7;                      // 127 records
+constexpr int TOP_RECORDS = (1 << TOP_LEVELS) - 1;
+__global__ void __launch_bounds__(256) ploc_record_places_kernel(int ni, TreeArrays T, int *__restrict__ record_of) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= ni) return;
+    int before = 0, depth = 0, child = id;
+    unsigned path = 0;        // the turns from the root down, the last one in bit 0
+    bool reachable = !T.info[id].w;
+    for (int node = T.parent[id]; node >= 0; node = T.parent[node]) {
+        const bool is_right = T.right[node] == child;
+        if (is_right) {
+            const int l = T.left[node];
+            before += l < 0 ? 0 : T.live[l];
+        }
+        before += 1;
+        if (depth < 32) path |= (is_right ? 1u : 0u) << depth;
+        ++depth;
+        if (T.info[node].w) reachable = false;
+        child = node;
+    }
+    if (!reachable) {
+        record_of[id] = -1;
+        return;
+    }
+    if (depth < TOP_LEVELS) {
+        int h = 0;
+        for (int k = depth - 1; k >= 0; --k) h = 2 * h + 1 + (int)((path >> k) & 1u);
+        record_of[id] = h;
+    } else {
+        record_of[id] = TOP_RECORDS + before;
     }
 }
 
-// The record of interior node i (DevScene::nodes): both children's boxes, their references, the split axis.
-__global__ void __launch_bounds__(256) records_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int n, const int *__restrict__ left,
-                                                       const int *__restrict__ right, const int *__restrict__ axis_bit, const float *__restrict__ node_box,
-                                                       float4 *__restrict__ nodes) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n - 1) return;
-    const int kids[2] = {left[i], right[i]};
+__global__ void __launch_bounds__(256) ploc_records_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int ni, TreeArrays T,
+                                                            const int *__restrict__ place, const int *__restrict__ first_entry, const int *__restrict__ record_of,
+                                                            float4 *__restrict__ nodes) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= ni || record_of[id] < 0) return;
+    const int kids[2] = {T.left[id], T.right[id]};
     float box[2][6];
     int ref[2];
     for (int k = 0; k < 2; ++k) {
-        const float *b = kids[k] < 0 ? bounds + 6 * (size_t)order[~kids[k]] : node_box + 6 * (size_t)kids[k];
+        const float *b = kids[k] < 0 ? bounds + 6 * (size_t)order[~kids[k]] : T.box + 6 * (size_t)kids[k];
         for (int a = 0; a < 6; ++a) box[k][a] = b[a];
-        ref[k] = kids[k] < 0 ? (int)(0x80000000u | (unsigned)~kids[k]) : kids[k];
+        if (kids[k] < 0)
+            ref[k] = (int)(0x80000000u | (unsigned)place[~kids[k]]);
+        else if (T.info[kids[k]].w)
+            ref[k] = (int)(0x80000000u | (unsigned)first_entry[kids[k]]);
+        else
+            ref[k] = record_of[kids[k]];
     }
-    float4 *o = nodes + 4 * (size_t)i;
+    float4 *o = nodes + 4 * (size_t)record_of[id];
     o[0] = make_float4(box[0][0], box[0][1], box[0][2], box[0][3]);
     o[1] = make_float4(box[0][4], box[0][5], box[1][0], box[1][1]);
     o[2] = make_float4(box[1][2], box[1][3], box[1][4], box[1][5]);
-    o[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(axis_bit[i]), 0.f);
+    o[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(T.axis_bit[id]), 0.f);
 }
 
-// Leaf entry and shading record of sorted position j (what rt_scene_create derives on the host for a tree that comes with
-// the scene: scaled vertex and edges as the reference computes them, src/shapes.cpp:22-33,236-237; the face normal).
+// Leaf entry and shading record of sorted position j, written to its place (what rt_scene_create derives on the host for a
+// tree that comes with the scene: scaled vertex and edges as the reference computes them, src/shapes.cpp:22-33,236-237;
+// the face normal).  The entry carries the box of its leaf and says whether it is the leaf's last.
 __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restrict__ in, const float *__restrict__ bounds, const unsigned *__restrict__ order, int n,
                                                        const rt_triangle *__restrict__ triangles, int n_triangles, const rt_instance *__restrict__ instances,
-                                                       float id_scale, float4 *__restrict__ prims, int4 *__restrict__ prim_meta) {
+                                                       float id_scale, const int *__restrict__ place, const int *__restrict__ leaf_of, const int *__restrict__ first_entry,
+                                                       const int4 *__restrict__ node_info, const float *__restrict__ node_box, float4 *__restrict__ prims,
+                                                       int4 *__restrict__ prim_meta) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const unsigned src = order[j];
     const rt_bvh_prim p = in[src];
-    const float *b = bounds + 6 * (size_t)src;
-    float4 *e = prims + PRIM_STRIDE * (size_t)j;
+    const int at = place ? place[j] : j, leaf = leaf_of ? leaf_of[j] : -1;
+    const float *b = leaf >= 0 ? node_box + 6 * (size_t)leaf : bounds + 6 * (size_t)src;
+    const bool last = leaf < 0 || at == first_entry[leaf] + node_info[leaf].y - 1;
+    const int last_bit = last ? PRIM_LAST_BIT : 0;
+    float4 *e = prims + PRIM_STRIDE * (size_t)at;
     int word;
     if (p.shape < n_triangles) {
         const rt_triangle &t = triangles[p.shape];
@@ -191,20 +314,20 @@ __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restr
         word = p.instance | (plain ? 0 : PRIM_XFORM_BIT);
         e[0] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
         e[1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
-        e[2] = make_float4(e2[2], __int_as_float(word | PRIM_LAST_BIT), b[0], b[1]);
+        e[2] = make_float4(e2[2], __int_as_float(word | last_bit), b[0], b[1]);
         const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
         const float len2 = (nx * nx + ny * ny) + nz * nz;
         const bool ok = len2 > 1e-12f;
         const float inv = ok ? rt_div(1.0f, rt_sqrt(len2)) : 0.0f;
-        prim_meta[2 * (size_t)j] = make_int4(word, p.shape, in_.ref_id, t.smooth ? 1 : 0);
-        prim_meta[2 * (size_t)j + 1] = make_int4(__float_as_int(ok ? nx * inv : 0.0f), __float_as_int(ok ? ny * inv : 0.0f), __float_as_int(ok ? nz * inv : 0.0f), 0);
+        prim_meta[2 * (size_t)at] = make_int4(word, p.shape, in_.ref_id, t.smooth ? 1 : 0);
+        prim_meta[2 * (size_t)at + 1] = make_int4(__float_as_int(ok ? nx * inv : 0.0f), __float_as_int(ok ? ny * inv : 0.0f), __float_as_int(ok ? nz * inv : 0.0f), 0);
     } else {
         const int sphere = p.shape - n_triangles;
         e[0] = make_float4(0, 0, 0, 0);
         e[1] = make_float4(0, 0, 0, 0);
-        e[2] = make_float4(0, __int_as_float((int)(0x80000000u | (unsigned)sphere | (unsigned)PRIM_LAST_BIT)), b[0], b[1]);
-        prim_meta[2 * (size_t)j] = make_int4(-1 - sphere, p.shape, 123456, 0);
-        prim_meta[2 * (size_t)j + 1] = make_int4(0, 0, 0, 0);
+        e[2] = make_float4(0, __int_as_float((int)(0x80000000u | (unsigned)sphere | (unsigned)last_bit)), b[0], b[1]);
+        prim_meta[2 * (size_t)at] = make_int4(-1 - sphere, p.shape, 123456, 0);
+        prim_meta[2 * (size_t)at + 1] = make_int4(0, 0, 0, 0);
     }
     e[3] = make_float4(b[2], b[3], b[4], b[5]);
 }
@@ -264,38 +387,82 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         }
         BVH_HIP_OK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys, order_in, order, n, 0, 63, 0));
     }
-    hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, d_prims, d_meta);
-    BVH_HIP_OK(hipGetLastError());
     if (n == 1) {   // the root is the one leaf
+        hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, (const int *)nullptr,
+                           (const int *)nullptr, (const int *)nullptr, (const int4 *)nullptr, (const float *)nullptr, d_prims, d_meta);
+        BVH_HIP_OK(hipGetLastError());
         out.root_ref = (int)0x80000000u;
     } else {
         const int ni = n - 1;
-        int *left = mem.get<int>((size_t)ni), *right = mem.get<int>((size_t)ni), *parent_of_node = mem.get<int>((size_t)ni), *parent_of_leaf = mem.get<int>((size_t)n),
-            *axis_bit = mem.get<int>((size_t)ni), *deepest = mem.get<int>(1);
-        float *node_box = mem.get<float>(6 * (size_t)ni);
-        unsigned *arrived = mem.get<unsigned>((size_t)ni);
-        float4 *d_nodes = mem.get<float4>(4 * (size_t)ni);
-        if (!left || !right || !parent_of_node || !parent_of_leaf || !axis_bit || !deepest || !node_box || !arrived || !d_nodes) {
+        TreeArrays T;
+        T.left = mem.get<int>((size_t)ni), T.right = mem.get<int>((size_t)ni), T.parent = mem.get<int>((size_t)ni), T.axis_bit = mem.get<int>((size_t)ni);
+        T.info = mem.get<int4>((size_t)ni), T.box = mem.get<float>(6 * (size_t)ni), T.parent_of_leaf = mem.get<int>((size_t)n);
+        T.live = mem.get<int>((size_t)ni);
+        int *record_of = mem.get<int>((size_t)ni);
+        const size_t n_records = (size_t)TOP_RECORDS + (size_t)ni;   // (room for every node; the walk reaches the ones that are not inside a leaf)
+        float4 *d_nodes = mem.get<float4>(4 * n_records);
+        // clusters of the current and of the next round; a round's flags and their scan
+        int *ref[2] = {mem.get<int>((size_t)n), mem.get<int>((size_t)n)};
+        int4 *info[2] = {mem.get<int4>((size_t)n), mem.get<int4>((size_t)n)};
+        float *cbox[2] = {mem.get<float>(6 * (size_t)n), mem.get<float>(6 * (size_t)n)};
+        int *nearest = mem.get<int>((size_t)n), *place = mem.get<int>((size_t)n), *leaf_of = mem.get<int>((size_t)n), *first_entry = mem.get<int>((size_t)ni);
+        unsigned long long *flags = mem.get<unsigned long long>((size_t)n + 1), *scanned = mem.get<unsigned long long>((size_t)n + 1);
+        size_t scan_bytes = 0;
+        BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, scanned, n + 1));
+        void *scan_temp = mem.get<char>(scan_bytes);
+        if (!T.left || !T.right || !T.parent || !T.axis_bit || !T.info || !T.box || !T.parent_of_leaf || !T.live || !record_of || !d_nodes || !ref[0] || !ref[1] || !info[0] || !info[1] ||
+            !cbox[0] || !cbox[1] || !nearest || !place || !leaf_of || !first_entry || !flags || !scanned || !scan_temp) {
             err = "rt_scene_create: out of device memory for the tree build";
             return 10;
         }
-        BVH_HIP_OK(hipMemsetAsync(arrived, 0, (size_t)ni * sizeof(unsigned), 0));
-        BVH_HIP_OK(hipMemsetAsync(deepest, 0, sizeof(int), 0));
         const unsigned blocks_i = (unsigned)((ni + 255) / 256);
-        hipLaunchKernelGGL(hierarchy_kernel, dim3(blocks_i), dim3(256), 0, 0, keys, n, left, right, parent_of_node, parent_of_leaf, axis_bit);
-        hipLaunchKernelGGL(fit_kernel, dim3(blocks_n), dim3(256), 0, 0, d_bounds, order, n, left, right, parent_of_node, parent_of_leaf, node_box, arrived, deepest);
-        hipLaunchKernelGGL(records_kernel, dim3(blocks_i), dim3(256), 0, 0, d_bounds, order, n, left, right, axis_bit, node_box, d_nodes);
-        BVH_HIP_OK(hipGetLastError());
-        BVH_HIP_OK(hipMemcpy(&out.depth, deepest, sizeof(int), hipMemcpyDeviceToHost));
+        const int radius = getenv("RT_GPU_BVH_RADIUS") ? std::max(1, std::min(256, atoi(getenv("RT_GPU_BVH_RADIUS")))) : 8;   // (1M-triangle scene, node visits per ray against the host tree: radius 2 +9 %, 4 +6 %, 8 +3 %, 16 +6 %, 48 +8 %)
+        hipLaunchKernelGGL(ploc_leaves_kernel, dim3(blocks_n), dim3(256), 0, 0, d_bounds, order, n, ref[0], cbox[0], info[0]);
+        int nc = n, made = 0, cur = 0;
+        while (nc > 1) {
+            const unsigned blocks_c = (unsigned)((nc + 255) / 256);
+            hipLaunchKernelGGL(ploc_nearest_kernel, dim3(blocks_c), dim3(256), 0, 0, cbox[cur], nc, radius, nearest);
+            hipLaunchKernelGGL(ploc_flag_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, nc, flags);
+            BVH_HIP_OK(hipMemsetAsync(flags + nc, 0, sizeof(unsigned long long), 0));   // the scan's last element: the totals
+            BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, flags, scanned, nc + 1));
+            hipLaunchKernelGGL(ploc_merge_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, flags, scanned, nc, made, ref[cur], cbox[cur], info[cur], ref[cur ^ 1],
+                               cbox[cur ^ 1], info[cur ^ 1], T);
+            BVH_HIP_OK(hipGetLastError());
+            unsigned long long totals = 0;
+            BVH_HIP_OK(hipMemcpy(&totals, scanned + nc, sizeof totals, hipMemcpyDeviceToHost));
+            const int survivors = (int)(totals & 0xffffffffull), merges = (int)(totals >> 32);
+            if (merges < 1 || survivors != nc - merges) {   // (the best pair of a round always choose each other)
+                err = "rt_scene_create: the clustering of the tree build made no progress";
+                return 10;
+            }
+            made += merges;
+            nc = survivors;
+            cur ^= 1;
+        }
+        int4 root_info;
+        BVH_HIP_OK(hipMemcpy(&root_info, info[cur], sizeof root_info, hipMemcpyDeviceToHost));
+        out.depth = root_info.x;
         if (out.depth > max_depth) {
             err = "rt_scene_create: the tree built on the device is " + std::to_string(out.depth) + " levels deep, more than the walk's stack of " +
                   std::to_string(max_depth) + " holds (many primitives with the same centre); build this scene's tree on the host";
             return 7;
         }
-        out.nodes = d_nodes;
-        out.n_interior = ni;
-        out.root_ref = 0;
-        mem.release(d_nodes);
+        hipLaunchKernelGGL(ploc_places_kernel, dim3(blocks_n), dim3(256), 0, 0, n, T, place, leaf_of, first_entry);
+        hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, place, leaf_of,
+                           first_entry, T.info, T.box, d_prims, d_meta);
+        BVH_HIP_OK(hipMemsetAsync(d_nodes, 0, 4 * n_records * sizeof(float4), 0));   // (places of the top that the tree does not fill are copied to LDS with the rest)
+        hipLaunchKernelGGL(ploc_record_places_kernel, dim3(blocks_i), dim3(256), 0, 0, ni, T, record_of);
+        hipLaunchKernelGGL(ploc_records_kernel, dim3(blocks_i), dim3(256), 0, 0, d_bounds, order, ni, T, place, first_entry, record_of, d_nodes);
+        BVH_HIP_OK(hipGetLastError());
+        if (root_info.w) {   // at most four primitives in all, cheaper as one leaf: the root is that leaf
+            out.root_ref = (int)0x80000000u;
+        } else {
+            out.nodes = d_nodes;
+            out.n_interior = ni;
+            out.n_top = TOP_RECORDS;
+            out.root_ref = 0;
+            mem.release(d_nodes);
+        }
     }
     BVH_HIP_OK(hipDeviceSynchronize());
     out.prims = d_prims;

@@ -2044,7 +2044,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             keep(dummy);
         }
         root_ref = built.root_ref;
-        s->dev.n_top = 0;   // the records are not in breadth-first order: no top of the tree in LDS
+        s->dev.n_top = built.n_top;   // the builder puts the top levels first, as the host's layout does
     } else {
         UP(nodes, nodes.data(), nodes.size());
         UP(prims, prims.data(), prims.size());

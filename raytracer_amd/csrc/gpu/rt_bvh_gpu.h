@@ -9,10 +9,11 @@
 namespace rt {
 
 struct DeviceBvh {
-    float4 *nodes = nullptr;      // two-box records (DevScene::nodes), n_interior of them; record 0 is the root
+    float4 *nodes = nullptr;      // two-box records (DevScene::nodes); record 0 is the root
     float4 *prims = nullptr;      // leaf entries (DevScene::prims), one per primitive, in leaf order
     int4 *prim_meta = nullptr;    // shading records (DevScene::prim_meta)
     int n_interior = 0;
+    int n_top = 0;                // the first n_top records are the top levels of the tree, level by level (DevScene::n_top)
     int root_ref = 0;
     int depth = 0;                // interior nodes on the longest root-to-leaf path
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};

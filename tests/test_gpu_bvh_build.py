@@ -39,7 +39,8 @@ def test_device_tree_finds_the_same_hits(name, scene_dir, repo_root, monkeypatch
     assert np.array_equal(s0 >= 0, s1 >= 0), "hit / miss differs"
     assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)), "closest distances differ"
     other = (s0 != s1) | (i0 != i1)                                    # same distance, another primitive: ties only
-    assert other.mean() <= 2e-3, f"{other.sum()} of {other.size} primary hits resolve to another primitive"
+    # (a 64x64 frame of two triangles that share a diagonal: every pixel on it is a tie)
+    assert other.mean() <= (5e-3 if name == "simple" else 2e-3), f"{other.sum()} of {other.size} primary hits resolve to another primitive"
     ref, st0 = R.Renderer(host_tree).render(cam)
     img, st1 = ren.render(cam)
     assert st0.primary_rays == st1.primary_rays
