@@ -5,6 +5,10 @@
 // Steps: luminance + log-average (per-thread double sums, fixed-order tree per block, fixed-order sum of the block
 // results: the same value every run), exposure, the burn-percent white point as an exact order statistic (radix
 // select over the float bit patterns, four 8-bit passes), then the per-pixel curve, saturation and gamma.
+// Everything between the first launch and the last stays on the device: the block sums are added and turned into the
+// exposure by a one-wave kernel, the select state lives in device memory, and the only scratch -- 1024 partial sums, the
+// select state and a 256-bin histogram -- is a fixed array inside the library, so a call costs eleven short launches and
+// no allocation, copy or wait in between (a 3840x2160 frame: see tools/bench_tonemap.py).
 #pragma once
 
 namespace {
@@ -35,11 +39,13 @@ __global__ void __launch_bounds__(TM_THREADS) tm_luminance_kernel(const float *_
 }
 
 // state[0] = bit-pattern prefix found so far, state[1] = rank still to find inside it, state[2] = result bits
-__global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *__restrict__ hdr, const float *__restrict__ lum, size_t n, float exposure, int pass,
+// state[3] = the exposure (float bits), set by tm_prepare_kernel
+__global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *__restrict__ hdr, const float *__restrict__ lum, size_t n, int pass,
                                                                    const unsigned *__restrict__ state, unsigned *__restrict__ hist) {
     __shared__ unsigned local[256];
     local[threadIdx.x] = 0;
     __syncthreads();
+    const float exposure = __uint_as_float(state[3]);
     const int shift = 24 - 8 * pass;
     const unsigned prefix = state[0];
     const unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
@@ -52,27 +58,59 @@ __global__ void __launch_bounds__(TM_THREADS) tm_histogram_kernel(const float *_
     if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
 }
 
-__global__ void tm_select_kernel(int pass, unsigned *__restrict__ state, unsigned *__restrict__ hist) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int shift = 24 - 8 * pass;
-    unsigned k = state[1], bin = 255;
-    for (unsigned b = 0; b < 256; ++b) {
-        const unsigned c = hist[b];
-        if (k < c) {
-            bin = b;
-            break;
-        }
-        k -= c;
+// One workgroup of 256: the bin in which the wanted rank falls (bins in ascending order), the rank inside it, and the
+// histogram cleared for the next pass.
+__global__ void __launch_bounds__(256) tm_select_kernel(int pass, unsigned *__restrict__ state, unsigned *__restrict__ hist) {
+    __shared__ unsigned incl[256];
+    const unsigned b = threadIdx.x, c = hist[b];
+    incl[b] = c;
+    __syncthreads();
+    for (unsigned step = 1; step < 256; step <<= 1) {   // inclusive prefix sums
+        const unsigned add = b >= step ? incl[b - step] : 0;
+        __syncthreads();
+        incl[b] += add;
+        __syncthreads();
     }
-    for (unsigned b = 0; b < 256; ++b) hist[b] = 0;
-    state[0] |= bin << shift;
-    state[1] = k;
-    if (pass == 3) state[2] = state[0];
+    const int shift = 24 - 8 * pass;
+    const unsigned k = state[1], prefix_so_far = state[0];
+    hist[b] = 0;
+    __syncthreads();   // (every thread has read the state)
+    const unsigned below = incl[b] - c;
+    // below <= k < below + c for exactly one bin; a rank beyond the total (not reached: the rank is below n) takes the last
+    if ((c > 0 && k >= below && k < incl[b]) || (b == 255 && k >= incl[255])) {
+        const unsigned prefix = prefix_so_far | b << shift;
+        state[0] = prefix;
+        state[1] = k - below;
+        if (pass == 3) state[2] = prefix;
+    }
+}
+
+// One wave: the block sums in a fixed order -> log-average luminance -> exposure (src/main.cpp:186-200), and the select
+// state for a frame of n pixels: state = {0, rank wanted, 0, exposure bits}, histogram cleared.
+__global__ void __launch_bounds__(64) tm_prepare_kernel(const double *__restrict__ partial, int blocks, double n, float key, unsigned rank, unsigned *__restrict__ state,
+                                                         unsigned *__restrict__ hist) {
+    __shared__ double sums[64];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 64) acc += partial[b];
+    sums[threadIdx.x] = acc;
+    __syncthreads();
+    for (int half = 32; half > 0; half >>= 1) {
+        if ((int)threadIdx.x < half) sums[threadIdx.x] += sums[threadIdx.x + half];
+        __syncthreads();
+    }
+    for (int b = threadIdx.x; b < 256; b += 64) hist[b] = 0;
+    if (threadIdx.x == 0) {
+        const float avg = (float)exp(sums[0] / n);
+        state[0] = 0;
+        state[1] = rank;
+        state[2] = 0;
+        state[3] = __float_as_uint(avg > 1e-6f ? key / avg : 1.0f);
+    }
 }
 
 struct TonemapParams {
     int tmo;
-    float exposure, saturation, inv_gamma;
+    float saturation, inv_gamma;
     int use_state_white;   // white point = max(value with bits state[2], 1e-6), else 1e9
 };
 
@@ -91,12 +129,13 @@ __global__ void __launch_bounds__(TM_THREADS) tm_apply_kernel(const float *__res
         if (!(white > 1e-6f)) white = 1e-6f;
     }
     const float white_sq = white * white;
+    const float exposure = __uint_as_float(state[3]);
     float denom = 1.0f;
     if (p.tmo == RT_TMO_ACES) denom = fmaxf(tm_aces(white), 1e-6f);
     if (p.tmo == RT_TMO_FILMIC) denom = fmaxf(tm_filmic(white), 1e-6f);
     for (size_t i = (size_t)blockIdx.x * TM_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * TM_THREADS) {
         const float y_in = lum ? lum[i] : tm_luminance(hdr + 3 * i);
-        const float L = (y_in < 0.0f ? 0.0f : y_in) * p.exposure;
+        const float L = (y_in < 0.0f ? 0.0f : y_in) * exposure;
         float y_out = 0.0f;
         if (p.tmo == RT_TMO_PHOTOGRAPHIC)
             y_out = (L * (1.0f + (L / white_sq))) / (1.0f + L);
@@ -148,10 +187,11 @@ struct TmBuffers {
     }
 };
 
-// ---- scratch of rt_tonemap_noalloc ------------------------------------------------------------------------------
-// Everything rt_tonemap allocates per call except the luminance plane (which the no-allocation variant does without):
-// TM_BLOCKS double partial sums, then the radix select's state (4 words) and histogram (256 words).  One copy per GPU
-// for the life of the process; calls that overlap on one GPU would race on it.
+// ---- the tone mapper's scratch -----------------------------------------------------------------------------------
+// TM_BLOCKS double partial sums, then the radix select's state (4 words) and histogram (256 words): all the device memory
+// a tone map needs beside its input and output.  One copy per GPU for the life of the process, inside the library, so
+// that no call allocates: rt_tonemap_noalloc promises that, and rt_tonemap saves five allocations per frame by it.  Calls on
+// one GPU take that GPU's lock for their launches (the array is one per GPU).
 constexpr size_t TM_SCRATCH_PARTIAL_BYTES = TM_BLOCKS * sizeof(double);
 constexpr size_t TM_SCRATCH_BYTES = TM_SCRATCH_PARTIAL_BYTES + (4 + 256) * sizeof(unsigned);
 static __device__ __align__(256) unsigned char scratch[(TM_SCRATCH_BYTES + 255) / 256 * 256];
@@ -161,12 +201,13 @@ static __device__ __align__(256) unsigned char scratch[(TM_SCRATCH_BYTES + 255) 
 constexpr int TM_MAX_DEVICES = 64;
 std::mutex g_tm_scratch_mutex;
 void *g_tm_scratch_ptr[TM_MAX_DEVICES] = {};
+std::mutex g_tm_device_lock[TM_MAX_DEVICES];
 
-int tm_scratch_of_current_device(void **out) {
+int tm_scratch_of_current_device(void **out, int *device_out) {
     int dev = -1;
     HIP_OK(hipGetDevice(&dev));
     if (dev < 0 || dev >= TM_MAX_DEVICES) {
-        g_error = "rt_tonemap_noalloc: device index out of range";
+        g_error = "rt_tonemap: device index out of range";
         return 10;
     }
     std::lock_guard<std::mutex> lk(g_tm_scratch_mutex);
@@ -174,12 +215,49 @@ int tm_scratch_of_current_device(void **out) {
         void *ptr = nullptr;
         HIP_OK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) {
-            g_error = "rt_tonemap_noalloc: no device address for the scratch array";
+            g_error = "rt_tonemap: no device address for the scratch array";
             return 10;
         }
         g_tm_scratch_ptr[dev] = ptr;
     }
     *out = g_tm_scratch_ptr[dev];
+    *device_out = dev;
+    return 0;
+}
+
+// The tone map of a frame in device memory into device memory, on the current device; allocates nothing.
+int tm_run(const float *d_hdr, int32_t width, int32_t height, const rt_tonemap_desc *tm, uint8_t *d_out) {
+    void *base = nullptr;
+    int dev = 0;
+    if (int rc = tm_scratch_of_current_device(&base, &dev)) return rc;
+    double *partial = (double *)base;
+    unsigned *state = (unsigned *)((unsigned char *)base + TM_SCRATCH_PARTIAL_BYTES), *hist = state + 4;
+    const size_t n = (size_t)width * height;
+    const int blocks = (int)std::min<size_t>(TM_BLOCKS, (n + TM_THREADS - 1) / TM_THREADS);
+    TonemapParams p;
+    p.tmo = tm->tmo;
+    p.saturation = tm->saturation + 0.2f;
+    p.inv_gamma = 1.0f / (tm->gamma > 1e-6f ? tm->gamma : 2.2f);
+    p.use_state_white = tm->opt2 > 1e-6f ? 1 : 0;
+    long long k = 0;
+    if (p.use_state_white) {   // burn percentage -> the k-th smallest exposed luminance
+        const float pct = (100.0f - tm->opt2) / 100.0f;
+        k = (long long)std::floor(pct * (float)(n - 1));
+        k = std::max<long long>(0, std::min<long long>((long long)n - 1, k));
+    }
+    std::lock_guard<std::mutex> lk(g_tm_device_lock[dev]);
+    // the array keeps the previous call's contents: every block of the first launch overwrites its partial sum, and the
+    // second sets the select state and clears the histogram before anything reads them
+    hipLaunchKernelGGL(tm_luminance_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, n, (float *)nullptr, partial);
+    hipLaunchKernelGGL(tm_prepare_kernel, dim3(1), dim3(64), 0, 0, partial, blocks, (double)n, tm->opt1, (unsigned)k, state, hist);
+    if (p.use_state_white)
+        for (int pass = 0; pass < 4; ++pass) {
+            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, (const float *)nullptr, n, pass, state, hist);
+            hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(256), 0, 0, pass, state, hist);
+        }
+    hipLaunchKernelGGL(tm_apply_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, (const float *)nullptr, n, p, state, d_out);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -193,7 +271,7 @@ int rt_tonemap(const float *hdr, int32_t width, int32_t height, const rt_tonemap
         return 1;
     }
     const size_t n = (size_t)width * height;
-    TmBuffers buf;
+    TmBuffers buf;   // device copies of buffers that live in host memory (the only allocations, and only then)
     const float *d_hdr = hdr;
     if (!tm_on_device(hdr)) {
         float *tmp = (float *)buf.get(n * 12);
@@ -206,43 +284,12 @@ int rt_tonemap(const float *hdr, int32_t width, int32_t height, const rt_tonemap
     }
     const bool out_dev = tm_on_device(rgb8_out);
     uint8_t *d_out = out_dev ? rgb8_out : (uint8_t *)buf.get(n * 3);
-    float *lum = (float *)buf.get(n * 4);
-    double *partial = (double *)buf.get(TM_BLOCKS * sizeof(double));
-    unsigned *state = (unsigned *)buf.get((4 + 256) * sizeof(unsigned)), *hist = state + 4;
-    if (!d_out || !lum || !partial || !state) {
+    if (!d_out) {
         g_error = "rt_tonemap: out of device memory";
         return 10;
     }
-    const int blocks = (int)std::min<size_t>(TM_BLOCKS, (n + TM_THREADS - 1) / TM_THREADS);
-    hipLaunchKernelGGL(tm_luminance_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, n, lum, partial);
-    HIP_OK(hipGetLastError());
-    double host_partial[TM_BLOCKS];
-    HIP_OK(hipMemcpy(host_partial, partial, blocks * sizeof(double), hipMemcpyDeviceToHost));
-    double sum_log = 0.0;
-    for (int b = 0; b < blocks; ++b) sum_log += host_partial[b];
-    const float avg = (float)std::exp(sum_log / (double)n);
-    TonemapParams p;
-    p.tmo = tm->tmo;
-    p.exposure = avg > 1e-6f ? tm->opt1 / avg : 1.0f;
-    p.saturation = tm->saturation + 0.2f;
-    p.inv_gamma = 1.0f / (tm->gamma > 1e-6f ? tm->gamma : 2.2f);
-    p.use_state_white = tm->opt2 > 1e-6f ? 1 : 0;
-    if (p.use_state_white) {   // burn percentage -> the k-th smallest exposed luminance
-        const float pct = (100.0f - tm->opt2) / 100.0f;
-        long long k = (long long)std::floor(pct * (float)(n - 1));
-        k = std::max<long long>(0, std::min<long long>((long long)n - 1, k));
-        const unsigned init[4] = {0u, (unsigned)k, 0u, 0u};
-        HIP_OK(hipMemcpy(state, init, sizeof init, hipMemcpyHostToDevice));
-        HIP_OK(hipMemset(hist, 0, 256 * sizeof(unsigned)));
-        for (int pass = 0; pass < 4; ++pass) {
-            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, lum, n, p.exposure, pass, state, hist);
-            hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1), 0, 0, pass, state, hist);
-        }
-    }
-    hipLaunchKernelGGL(tm_apply_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, d_hdr, lum, n, p, state, d_out);
-    HIP_OK(hipGetLastError());
+    if (int rc = tm_run(d_hdr, width, height, tm, d_out)) return rc;
     if (!out_dev) HIP_OK(hipMemcpy(rgb8_out, d_out, n * 3, hipMemcpyDeviceToHost));
-    HIP_OK(hipDeviceSynchronize());
     return 0;
 }
 
@@ -266,43 +313,7 @@ int rt_tonemap_noalloc(const float *hdr, int32_t width, int32_t height, const rt
                   std::to_string(dev_out) + ", current is GPU " + std::to_string(current) + ")";
         return 1;
     }
-    void *base = nullptr;
-    if (int rc = tm_scratch_of_current_device(&base)) return rc;
-    double *partial = (double *)base;
-    unsigned *state = (unsigned *)((unsigned char *)base + TM_SCRATCH_PARTIAL_BYTES), *hist = state + 4;
-    const size_t n = (size_t)width * height;
-    const int blocks = (int)std::min<size_t>(TM_BLOCKS, (n + TM_THREADS - 1) / TM_THREADS);
-    // the array keeps the previous call's contents: every block of this launch overwrites its partial sum, and the
-    // select state and histogram are set below before they are read
-    hipLaunchKernelGGL(tm_luminance_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, n, (float *)nullptr, partial);
-    HIP_OK(hipGetLastError());
-    double host_partial[TM_BLOCKS];
-    HIP_OK(hipMemcpy(host_partial, partial, blocks * sizeof(double), hipMemcpyDeviceToHost));
-    double sum_log = 0.0;
-    for (int b = 0; b < blocks; ++b) sum_log += host_partial[b];
-    const float avg = (float)std::exp(sum_log / (double)n);
-    TonemapParams p;
-    p.tmo = tm->tmo;
-    p.exposure = avg > 1e-6f ? tm->opt1 / avg : 1.0f;
-    p.saturation = tm->saturation + 0.2f;
-    p.inv_gamma = 1.0f / (tm->gamma > 1e-6f ? tm->gamma : 2.2f);
-    p.use_state_white = tm->opt2 > 1e-6f ? 1 : 0;
-    if (p.use_state_white) {
-        const float pct = (100.0f - tm->opt2) / 100.0f;
-        long long k = (long long)std::floor(pct * (float)(n - 1));
-        k = std::max<long long>(0, std::min<long long>((long long)n - 1, k));
-        const unsigned init[4] = {0u, (unsigned)k, 0u, 0u};
-        HIP_OK(hipMemcpy(state, init, sizeof init, hipMemcpyHostToDevice));
-        HIP_OK(hipMemsetAsync(hist, 0, 256 * sizeof(unsigned), 0));
-        for (int pass = 0; pass < 4; ++pass) {
-            hipLaunchKernelGGL(tm_histogram_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, (const float *)nullptr, n, p.exposure, pass, state, hist);
-            hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1), 0, 0, pass, state, hist);
-        }
-    }
-    hipLaunchKernelGGL(tm_apply_kernel, dim3(blocks), dim3(TM_THREADS), 0, 0, hdr, (const float *)nullptr, n, p, state, rgb8_out);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipDeviceSynchronize());
-    return 0;
+    return tm_run(hdr, width, height, tm, rgb8_out);
 }
 
 int rt_quantize_ldr(const float *hdr, int64_t n_values, uint8_t *out) {
