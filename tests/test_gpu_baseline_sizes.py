@@ -68,3 +68,35 @@ def test_c4_path_traced_scene_480x270_16spp(scene_dir, monkeypatch):
     cam = sc.camera(0)
     assert sc.desc.n_triangles == 1008202
     same_image(sc, cam)
+
+
+@pytest.mark.parametrize("env_extra", [{}, {"RT_GPUS_DEVICES": "0,0,0,0", "RT_GPUS": "2"}], ids=["one_gpu", "two_teams_of_two_on_one_gpu"])
+def test_c5_animation_120_frames_1080p(tmp_path, repo_root, env_extra):
+    """Config 5 at its workload: 120 scene files (the 70 K-triangle mesh, the camera orbiting, 1920x1080) through the
+    command line's loader / render / writer pipeline -- on this box's one GPU, and as the frame-and-tile parallel run of
+    four GPUs rehearsed on it (two teams of two ranks take the frames in turn, each frame split by tiles and gathered).
+    All 120 PNGs are written; six of them are compared with a render through the C ABI, byte for byte."""
+    import json
+    import math
+    import subprocess
+    from test_host import png_pixels
+    frames = str(tmp_path / "frames")
+    base = scenegen.write_mesh_scene(frames, name="anim_0000", n=188, width=1920, height=1080)
+    doc = json.load(open(base))
+    n = 120
+    for k in range(n):
+        cam = doc["Scene"]["Cameras"]["Camera"]
+        a = 2 * math.pi * k / n
+        cam["Position"] = f"{3.2 * math.sin(a):.5f} 0.5 {3.2 * math.cos(a):.5f}"
+        cam["ImageName"] = f"anim_{k:04d}.png"
+        json.dump(doc, open(os.path.join(frames, f"anim_{k:04d}.json"), "w"))
+    r = subprocess.run([os.path.join(repo_root, "raytracer"), frames], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env_extra))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sum("rendering done:" in l for l in r.stdout.splitlines()) == n
+    written = sorted(f for f in os.listdir(tmp_path / "outputs") if f.endswith(".png"))
+    assert written == [f"anim_{k:04d}.png" for k in range(n)]
+    for k in (0, 17, 45, 60, 101, 119):
+        sc = R.Scene(os.path.join(frames, f"anim_{k:04d}.json"))
+        img, _ = R.Renderer(sc).render(sc.camera(0))
+        assert np.array_equal(png_pixels(str(tmp_path / "outputs" / f"anim_{k:04d}.png")), R.gpu_quantize_ldr(img)[::-1]), k
