@@ -88,3 +88,32 @@ def test_million_triangle_scene_on_the_device_tree(scene_dir, monkeypatch):
     ref, _ = R.Renderer(host_tree).render(cam)
     err = (np.abs(img - ref) / np.maximum(np.abs(ref), 1 / 255)).max(axis=2)
     assert (err > 1e-5).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5, 9])
+def test_device_tree_of_a_handful_of_primitives(n_tris, tmp_path, monkeypatch):
+    """One primitive (the root is a leaf), two or three (the whole tree collapses into one leaf), five and nine (the
+    first real interior nodes): the device-built tree finds the host tree's hits."""
+    import json
+    rng = np.random.default_rng(n_tris)
+    verts, faces = [], []
+    for k in range(n_tris):
+        c = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), -2.0 - 0.1 * k])
+        for d in ((-0.3, -0.3, 0), (0.3, -0.3, 0), (0, 0.3, 0)):
+            verts.append(c + np.array(d))
+        faces.append(f"{3 * k + 1} {3 * k + 2} {3 * k + 3}")
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "simple.json")))
+    doc["Scene"]["VertexData"]["_data"] = "  ".join(f"{v[0]:.4f} {v[1]:.4f} {v[2]:.4f}" for v in verts)
+    doc["Scene"]["Objects"] = {"Mesh": {"_id": "1", "Material": "1", "Faces": {"_data": "  ".join(faces)}}}
+    path = str(tmp_path / "few.json")
+    json.dump(doc, open(path, "w"))
+    host_tree, no_tree = two_scenes(path, monkeypatch)
+    cam = host_tree.camera(0)
+    s0, i0, t0, _ = R.Renderer(host_tree).trace_primary(cam)
+    ren = R.Renderer(no_tree)
+    s1, i1, t1, _ = ren.trace_primary(cam)
+    assert (s0 >= 0).sum() > 20
+    assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and np.array_equal(s0, s1)   # (distinct depths: no ties)
+    img0, _ = R.Renderer(host_tree).render(cam)
+    img1, _ = ren.render(cam)
+    assert np.array_equal(img0, img1)
