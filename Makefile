@@ -16,7 +16,7 @@ GPU_HDRS = $(wildcard raytracer_amd/csrc/gpu/*.h) include/gpu_render.h
 build/render.o: raytracer_amd/csrc/gpu/render.hip $(GPU_HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-build/bvh_gpu.o: raytracer_amd/csrc/gpu/bvh_gpu.hip raytracer_amd/csrc/gpu/rt_bvh_gpu.h raytracer_amd/csrc/gpu/rt_device.h raytracer_amd/csrc/gpu/rt_math.h include/gpu_render.h
+build/bvh_gpu.o: raytracer_amd/csrc/gpu/bvh_gpu.hip raytracer_amd/csrc/gpu/rt_bvh_gpu.h raytracer_amd/csrc/gpu/rt_device.h raytracer_amd/csrc/gpu/rt_devmem.h raytracer_amd/csrc/gpu/rt_math.h include/gpu_render.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 raytracer_amd/librt_gpu.so: build/render.o build/bvh_gpu.o

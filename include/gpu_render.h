@@ -304,6 +304,10 @@ int32_t rt_shadow_order_free(const rt_scene_desc *desc);
  * materials without textures runs of calculate_color, trace_rec and path_trace (src/ray_trace.cpp:154-447, 646-869, 871-1139):
  * no texture lookups, no mirror, conductor or dielectric branch.  RT_PLAIN_SHADING=0 at rt_scene_create: never. */
 int32_t rt_scene_plain_shading(const rt_scene *scene);
+/* Test hook: 1 when the scene holds the four-box records that uncounted frames walk instead of bvh::intersect's node-by-node
+ * records (src/bvh.cpp:383-480) -- made on the host once the scene has traced enough rays to repay them (RT_WIDE_NODES=1: at
+ * rt_scene_create), or with the tree when that is built on the device; RT_WIDE_NODES=0: never. */
+int32_t rt_scene_wide_records(const rt_scene *scene);
 
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders

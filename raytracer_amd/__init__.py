@@ -190,6 +190,12 @@ class Renderer:
         self._g.rt_scene_plain_shading.argtypes = [C.c_void_p]
         return bool(self._g.rt_scene_plain_shading(self._ptr))
 
+    def wide_records(self):
+        """True when the scene holds the four-box records that uncounted frames walk (rt_scene_wide_records)."""
+        self._g.rt_scene_wide_records.restype = C.c_int32
+        self._g.rt_scene_wide_records.argtypes = [C.c_void_p]
+        return bool(self._g.rt_scene_wide_records(self._ptr))
+
     def set_counters(self, enabled):
         self._check(self._g.rt_set_counters(self._ptr, 1 if enabled else 0), "rt_set_counters")
 

@@ -21,11 +21,13 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
 #include <cstring>
 #include <vector>
 
 #include "rt_bvh_gpu.h"
 #include "rt_device.h"
+#include "rt_devmem.h"
 
 namespace rt {
 
@@ -40,14 +42,30 @@ namespace {
         }                                                                     \
     } while (0)
 
-struct Scratch {   // device buffers of one build, released on every return path
+// RT_CREATE_TIMING: stage times of a build on stderr (diagnostic; every mark waits for the device)
+struct StageClock {
+    const bool on = getenv("RT_CREATE_TIMING") != nullptr;
+    std::chrono::high_resolution_clock::time_point last = std::chrono::high_resolution_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::high_resolution_clock::now();
+        fprintf(stderr, "[create] tree build: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+struct Scratch {   // device buffers of one build (from the device's block cache), released on every return path
     std::vector<void *> owned;
     ~Scratch() {
-        for (void *p : owned) (void)hipFree(p);
+        StageClock clock;
+        (void)hipDeviceSynchronize();   // (a build that gave up may still have launches in flight; blocks go back only when idle)
+        for (void *p : owned) device_blocks().free(p);
+        clock.mark("buffers released");
     }
     template <class T> T *get(size_t n) {
-        void *p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        void *p = device_blocks().alloc(std::max<size_t>(n, 1) * sizeof(T));
+        if (!p) return nullptr;
         owned.push_back(p);
         return (T *)p;
     }
@@ -148,6 +166,9 @@ struct TreeArrays {   // per interior node id (in the order the nodes are made: 
     int4 *info;       // as a cluster's
     float *box;
     int *parent_of_leaf;   // per sorted position
+    int4 *wide;       // for the four-box records: {reachable interior nodes of the subtree an even number of steps below this
+                      // node (itself included), an odd number of steps below, stack entries a walk needs below this node
+                      // were it the head of a record, unused}
 };
 
 __global__ void __launch_bounds__(256) ploc_merge_kernel(const int *__restrict__ nearest, const unsigned long long *__restrict__ flags,
@@ -195,6 +216,31 @@ __global__ void __launch_bounds__(256) ploc_merge_kernel(const int *__restrict__
     const int4 mine = make_int4(leaf ? 0 : 1 + max(ii.x, ij.x), count, __float_as_int(cost), leaf ? 1 : 0);
     T.info[id] = mine;
     T.live[id] = leaf ? 0 : 1 + (l < 0 ? 0 : T.live[l]) + (r < 0 ? 0 : T.live[r]);
+    {   // (children and grandchildren were made in earlier rounds)
+        int4 w = make_int4(0, 0, 0, 0);
+        if (!leaf) {
+            const int4 wl = l < 0 ? make_int4(0, 0, 0, 0) : T.wide[l], wr = r < 0 ? make_int4(0, 0, 0, 0) : T.wide[r];
+            w.x = 1 + wl.y + wr.y;
+            w.y = wl.x + wr.x;
+            // a record headed here holds a leaf child itself and an interior child's two children: the walk keeps all but one
+            // of them waiting while it goes down the deepest (rt_wide.h, build_wide_nodes)
+            int present = 0, deepest = 0;
+            const int kids[2] = {l, r};
+            for (int k = 0; k < 2; ++k) {
+                const int c = kids[k];
+                if (c < 0 || T.info[c].w) {
+                    present += 1;
+                    continue;
+                }
+                present += 2;
+                const int grand[2] = {T.left[c], T.right[c]};
+                for (int g = 0; g < 2; ++g)
+                    if (grand[g] >= 0 && !T.info[grand[g]].w) deepest = max(deepest, T.wide[grand[g]].z);
+            }
+            w.z = present - 1 + deepest;
+        }
+        T.wide[id] = w;
+    }
     ref_out[place] = id;
     info_out[place] = mine;
 }
@@ -227,24 +273,55 @@ __global__ void __launch_bounds__(256) ploc_places_kernel(int n, TreeArrays T, i
 // root to find both numbers.  Nodes inside a subtree that became a leaf get no record.
 constexpr int TOP_LEVELS = 7;                      // 127 records
 constexpr int TOP_RECORDS = (1 << TOP_LEVELS) - 1;
-__global__ void __launch_bounds__(256) ploc_record_places_kernel(int ni, TreeArrays T, int *__restrict__ record_of) {
+// The first records of the four-box tree, for the trace kernel's LDS copy: the heads a breadth-first walk from the root meets
+// first (the order build_wide_nodes of rt_wide.h gives the host's tree).  One thread: at most TOP_RECORDS short steps.
+// wide_top[] is -1 everywhere when the kernel starts; queue[] holds 4 * TOP_RECORDS + 4 entries.
+__device__ __forceinline__ bool one_leaf(const TreeArrays &T, int c) { return c < 0 || T.info[c].w != 0; }
+__global__ void wide_top_kernel(int root, TreeArrays T, int *__restrict__ wide_top, int *__restrict__ queue, int *__restrict__ n_top_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int size = 0, count = 0;
+    queue[size++] = root;
+    for (int at = 0; at < size && count < TOP_RECORDS; ++at) {
+        const int i = queue[at];
+        wide_top[i] = count++;
+        const int kids[2] = {T.left[i], T.right[i]};
+        for (int k = 0; k < 2; ++k) {
+            if (one_leaf(T, kids[k])) continue;
+            const int grand[2] = {T.left[kids[k]], T.right[kids[k]]};
+            for (int g = 0; g < 2; ++g)
+                if (!one_leaf(T, grand[g])) queue[size++] = grand[g];
+        }
+    }
+    *n_top_out = count;
+}
+
+__global__ void __launch_bounds__(256) ploc_record_places_kernel(int ni, TreeArrays T, const int *__restrict__ wide_top, int *__restrict__ record_of,
+                                                                  int *__restrict__ wide_record_of) {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= ni) return;
     int before = 0, depth = 0, child = id;
+    int heads_before = 0;     // record heads before this node in the same order, were this node a head (an even number of steps below the root)
     unsigned path = 0;        // the turns from the root down, the last one in bit 0
     bool reachable = !T.info[id].w;
     for (int node = T.parent[id]; node >= 0; node = T.parent[node]) {
         const bool is_right = T.right[node] == child;
+        const bool even_step = (depth & 1) != 0;   // this ancestor is depth + 1 steps up
         if (is_right) {
             const int l = T.left[node];
-            before += l < 0 ? 0 : T.live[l];
+            if (l >= 0) {
+                before += T.live[l];
+                const int4 w = T.wide[l];            // (the sibling is one step nearer than the ancestor)
+                heads_before += even_step ? w.y : w.x;
+            }
         }
         before += 1;
+        heads_before += even_step ? 1 : 0;
         if (depth < 32) path |= (is_right ? 1u : 0u) << depth;
         ++depth;
         if (T.info[node].w) reachable = false;
         child = node;
     }
+    if (wide_record_of) wide_record_of[id] = !reachable || (depth & 1) ? -1 : (wide_top[id] >= 0 ? wide_top[id] : TOP_RECORDS + heads_before);
     if (!reachable) {
         record_of[id] = -1;
         return;
@@ -283,9 +360,103 @@ __global__ void __launch_bounds__(256) ploc_records_kernel(const float *__restri
     o[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(T.axis_bit[id]), 0.f);
 }
 
-// Leaf entry and shading record of sorted position j, written to its place (what rt_scene_create derives on the host for a
-// tree that comes with the scene: scaled vertex and edges as the reference computes them, src/shapes.cpp:22-33,236-237;
-// the face normal).  The entry carries the box of its leaf and says whether it is the leaf's last.
+// The four-box record headed by node `id` (DevScene::wnodes; the host's fill_wide_record in rt_wide.h makes the same record
+// from the same boxes): a child that is a leaf fills one slot, an interior child gives its own two children, the boxes are
+// bytes on a grid of power-of-two steps from the lowest corner, rounded outwards -- the decoded coordinate is
+// fmaf(q, step, origin) here and in the trace kernel, and is never inside the exact box.  *unsound is set when a record
+// cannot be made (a grid step beyond the exponent range).
+__device__ bool quantise_axis(const float lo_of[4], const float hi_of[4], const bool present[4], float &origin, float &step_out, unsigned &qlo, unsigned &qhi) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int k = 0; k < 4; ++k)
+        if (present[k]) lo = fminf(lo, lo_of[k]), hi = fmaxf(hi, hi_of[k]);
+    origin = lo;
+    // the grid step is never so small that origin + 255 steps rounds back to the origin: an empty slot's inverted box
+    // (255..0) then misses on every axis the ray moves along
+    int e = max(-100, ilogbf(fmaxf(fmaxf(fabsf(lo), fabsf(hi)), 1e-30f)) - 22);
+    const double extent = (double)hi - (double)lo;
+    if (extent > 0) e = max(ilogb(extent / 255.0) + 1, e);   // 2^e > extent / 255
+    for (;; ++e) {   // the smallest step with which every box fits 0..255
+        if (e > 126) return false;
+        const float step = ldexpf(1.0f, e);
+        const double per_step = ldexp(1.0, -e);   // a power of two: the products below are exact
+        unsigned lo_bytes = 0, hi_bytes = 0;
+        bool fits = true;
+        for (int k = 0; k < 4 && fits; ++k) {
+            if (!present[k]) {
+                lo_bytes |= 255u << (8 * k);
+                continue;
+            }
+            int ql = (int)fmin(255.0, floor(((double)lo_of[k] - (double)lo) * per_step));
+            while (ql > 0 && fmaf((float)ql, step, lo) > lo_of[k]) --ql;
+            int qh = (int)fmin(256.0, ceil(((double)hi_of[k] - (double)lo) * per_step));
+            while (qh <= 255 && fmaf((float)qh, step, lo) < hi_of[k]) ++qh;
+            if (qh > 255) fits = false;
+            lo_bytes |= (unsigned)ql << (8 * k);
+            hi_bytes |= (unsigned)(qh & 255) << (8 * k);
+        }
+        if (fits) {
+            qlo = lo_bytes, qhi = hi_bytes, step_out = step;
+            return true;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ploc_wide_records_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int ni, TreeArrays T,
+                                                                 const int *__restrict__ place, const int *__restrict__ first_entry,
+                                                                 const int *__restrict__ wide_record_of, float4 *__restrict__ wnodes, int *__restrict__ unsound) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= ni || wide_record_of[id] < 0) return;
+    const int kids[2] = {T.left[id], T.right[id]};
+    int slot[4];                 // node or ~position; slot_used says whether there is one
+    bool present[4];
+    unsigned head_bits = (unsigned)T.axis_bit[id];
+    for (int k = 0; k < 2; ++k) {
+        const int c = kids[k];
+        if (one_leaf(T, c)) {
+            slot[2 * k] = c, present[2 * k] = true;
+            slot[2 * k + 1] = 0, present[2 * k + 1] = false;
+        } else {
+            slot[2 * k] = T.left[c], slot[2 * k + 1] = T.right[c];
+            present[2 * k] = present[2 * k + 1] = true;
+            head_bits |= (unsigned)T.axis_bit[c] << (3 + 3 * k);
+        }
+    }
+    unsigned ref[4];
+    float lo_of[3][4], hi_of[3][4];
+    for (int k = 0; k < 4; ++k) {
+        if (!present[k]) {
+            ref[k] = 0x40000000u;   // the walk's "pop" reference, harmless if ever followed
+            for (int a = 0; a < 3; ++a) lo_of[a][k] = hi_of[a][k] = 0.0f;
+            continue;
+        }
+        const int c = slot[k];
+        const float *b = c < 0 ? bounds + 6 * (size_t)order[~c] : T.box + 6 * (size_t)c;
+        for (int a = 0; a < 3; ++a) lo_of[a][k] = b[a], hi_of[a][k] = b[3 + a];
+        if (c < 0)
+            ref[k] = 0x80000000u | (unsigned)place[~c];
+        else if (T.info[c].w)
+            ref[k] = 0x80000000u | (unsigned)first_entry[c];
+        else
+            ref[k] = (unsigned)wide_record_of[c];
+    }
+    float origin[3], step[3];
+    unsigned qlo[3], qhi[3];
+    for (int a = 0; a < 3; ++a)
+        if (!quantise_axis(lo_of[a], hi_of[a], present, origin[a], step[a], qlo[a], qhi[a])) {
+            *unsound = 1;
+            return;
+        }
+    float4 *o = wnodes + 4 * (size_t)wide_record_of[id];
+    o[0] = make_float4(origin[0], origin[1], origin[2], __uint_as_float(__float_as_uint(step[0]) | head_bits));
+    o[1] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    o[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qhi[0]), __uint_as_float(qlo[1]), __uint_as_float(qhi[1]));
+    o[3] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[2]), step[1], step[2]);
+}
+
+// Leaf entry and shading record of sorted position j, written to its place: scaled vertex and edges as the reference
+// computes them (src/shapes.cpp:22-33,236-237), the face normal.  For a tree built here the entry carries the box of its leaf
+// and says whether it is the leaf's last; for a tree that came with the scene (`order`, `bounds`, `place` null: entry j is
+// primitive j) leaf_boxes_kernel adds both afterwards.
 __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restrict__ in, const float *__restrict__ bounds, const unsigned *__restrict__ order, int n,
                                                        const rt_triangle *__restrict__ triangles, int n_triangles, const rt_instance *__restrict__ instances,
                                                        float id_scale, const int *__restrict__ place, const int *__restrict__ leaf_of, const int *__restrict__ first_entry,
@@ -293,11 +464,12 @@ __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restr
                                                        int4 *__restrict__ prim_meta) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const unsigned src = order[j];
+    const unsigned src = order ? order[j] : (unsigned)j;
     const rt_bvh_prim p = in[src];
     const int at = place ? place[j] : j, leaf = leaf_of ? leaf_of[j] : -1;
-    const float *b = leaf >= 0 ? node_box + 6 * (size_t)leaf : bounds + 6 * (size_t)src;
-    const bool last = leaf < 0 || at == first_entry[leaf] + node_info[leaf].y - 1;
+    const float no_box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float *b = leaf >= 0 ? node_box + 6 * (size_t)leaf : (bounds ? bounds + 6 * (size_t)src : no_box);
+    const bool last = bounds && (leaf < 0 || at == first_entry[leaf] + node_info[leaf].y - 1);
     const int last_bit = last ? PRIM_LAST_BIT : 0;
     float4 *e = prims + PRIM_STRIDE * (size_t)at;
     int word;
@@ -332,10 +504,43 @@ __global__ void __launch_bounds__(256) entries_kernel(const rt_bvh_prim *__restr
     e[3] = make_float4(b[2], b[3], b[4], b[5]);
 }
 
+// ---- records of a tree that came with the scene ------------------------------------------------------------------------
+// Every entry of a leaf carries the leaf's box, the last one the end mark.
+__global__ void __launch_bounds__(256) leaf_boxes_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, float4 *__restrict__ prims) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const rt_bvh_node n = nodes[i];
+    for (int k = 0; k < n.n_prims; ++k) {
+        float4 *e = prims + PRIM_STRIDE * (size_t)(n.offset + k);
+        float4 w = e[2];
+        w.z = n.bmin[0], w.w = n.bmin[1];
+        if (k == n.n_prims - 1) w.y = __int_as_float(__float_as_int(w.y) | PRIM_LAST_BIT);
+        e[2] = w;
+        e[3] = make_float4(n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]);
+    }
+}
+
+// The two-box record of interior node i at the place `record_of[i]` gives it: both children's boxes, their references (a
+// record, or a leaf's first entry) and the split axis.
+__global__ void __launch_bounds__(256) node_records_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, const int *__restrict__ record_of, float4 *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const rt_bvh_node n = nodes[i];
+    if (n.n_prims != 0) return;
+    const rt_bvh_node L = nodes[i + 1], R = nodes[n.offset];
+    const int lr = L.n_prims == 0 ? record_of[i + 1] : (int)(0x80000000u | (unsigned)L.offset);
+    const int rr = R.n_prims == 0 ? record_of[n.offset] : (int)(0x80000000u | (unsigned)R.offset);
+    float4 *o = out + 4 * (size_t)record_of[i];
+    o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
+    o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
+    o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+    o[3] = make_float4(__int_as_float(lr), __int_as_float(rr), __int_as_float(1 << n.axis), 0.f);
+}
+
 }  // namespace
 
 int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, const rt_triangle *d_triangles, int n_triangles, const rt_instance *d_instances,
-                        float id_scale, int max_depth, DeviceBvh &out, std::string &err) {
+                        float id_scale, int max_depth, int wide_stack_entries, DeviceBvh &out, std::string &err) {
     out = DeviceBvh();
     if (n <= 0) return 0;
     // box of the scene and of the primitives' centres (one pass on the host, while the arrays are at hand)
@@ -358,6 +563,8 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
     }
     memcpy(out.root_min, smin, sizeof smin);
     memcpy(out.root_max, smax, sizeof smax);
+    StageClock clock;
+    clock.mark("boxes of the scene (host)");
     Scratch mem;
     rt_bvh_prim *d_in = mem.get<rt_bvh_prim>((size_t)n);
     float *d_bounds = mem.get<float>(6 * (size_t)n);
@@ -371,6 +578,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
     }
     BVH_HIP_OK(hipMemcpy(d_in, prims, (size_t)n * sizeof(rt_bvh_prim), hipMemcpyHostToDevice));
     BVH_HIP_OK(hipMemcpy(d_bounds, bounds, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    clock.mark("primitives uploaded");
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
     const float3 lo = make_float3(cmin[0], cmin[1], cmin[2]);
     const float3 inv = make_float3(cmax[0] > cmin[0] ? 1.0f / (cmax[0] - cmin[0]) : 0.0f, cmax[1] > cmin[1] ? 1.0f / (cmax[1] - cmin[1]) : 0.0f,
@@ -387,6 +595,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         }
         BVH_HIP_OK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys, order_in, order, n, 0, 63, 0));
     }
+    clock.mark("ordered along the curve");
     if (n == 1) {   // the root is the one leaf
         hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, (const int *)nullptr,
                            (const int *)nullptr, (const int *)nullptr, (const int4 *)nullptr, (const float *)nullptr, d_prims, d_meta);
@@ -398,7 +607,9 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         T.left = mem.get<int>((size_t)ni), T.right = mem.get<int>((size_t)ni), T.parent = mem.get<int>((size_t)ni), T.axis_bit = mem.get<int>((size_t)ni);
         T.info = mem.get<int4>((size_t)ni), T.box = mem.get<float>(6 * (size_t)ni), T.parent_of_leaf = mem.get<int>((size_t)n);
         T.live = mem.get<int>((size_t)ni);
-        int *record_of = mem.get<int>((size_t)ni);
+        T.wide = mem.get<int4>((size_t)ni);
+        int *record_of = mem.get<int>((size_t)ni), *wide_record_of = mem.get<int>((size_t)ni), *wide_top = mem.get<int>((size_t)ni);
+        int *wide_queue = mem.get<int>(4 * (size_t)TOP_RECORDS + 4), *wide_words = mem.get<int>(2);   // {records of the top, 1 when a record could not be made}
         const size_t n_records = (size_t)TOP_RECORDS + (size_t)ni;   // (room for every node; the walk reaches the ones that are not inside a leaf)
         float4 *d_nodes = mem.get<float4>(4 * n_records);
         // clusters of the current and of the next round; a round's flags and their scan
@@ -410,13 +621,15 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         size_t scan_bytes = 0;
         BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, scanned, n + 1));
         void *scan_temp = mem.get<char>(scan_bytes);
-        if (!T.left || !T.right || !T.parent || !T.axis_bit || !T.info || !T.box || !T.parent_of_leaf || !T.live || !record_of || !d_nodes || !ref[0] || !ref[1] || !info[0] || !info[1] ||
+        if (!T.left || !T.right || !T.parent || !T.axis_bit || !T.info || !T.box || !T.parent_of_leaf || !T.live || !T.wide || !record_of || !wide_record_of || !wide_top ||
+            !wide_queue || !wide_words || !d_nodes || !ref[0] || !ref[1] || !info[0] || !info[1] ||
             !cbox[0] || !cbox[1] || !nearest || !place || !leaf_of || !first_entry || !flags || !scanned || !scan_temp) {
             err = "rt_scene_create: out of device memory for the tree build";
             return 10;
         }
         const unsigned blocks_i = (unsigned)((ni + 255) / 256);
         const int radius = getenv("RT_GPU_BVH_RADIUS") ? std::max(1, std::min(256, atoi(getenv("RT_GPU_BVH_RADIUS")))) : 8;   // (1M-triangle scene, node visits per ray against the host tree: radius 2 +9 %, 4 +6 %, 8 +3 %, 16 +6 %, 48 +8 %)
+        clock.mark("buffers of the clustering");
         hipLaunchKernelGGL(ploc_leaves_kernel, dim3(blocks_n), dim3(256), 0, 0, d_bounds, order, n, ref[0], cbox[0], info[0]);
         int nc = n, made = 0, cur = 0;
         while (nc > 1) {
@@ -439,6 +652,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
             nc = survivors;
             cur ^= 1;
         }
+        clock.mark("clustered");
         int4 root_info;
         BVH_HIP_OK(hipMemcpy(&root_info, info[cur], sizeof root_info, hipMemcpyDeviceToHost));
         out.depth = root_info.x;
@@ -451,8 +665,28 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         hipLaunchKernelGGL(entries_kernel, dim3(blocks_n), dim3(256), 0, 0, d_in, d_bounds, order, n, d_triangles, n_triangles, d_instances, id_scale, place, leaf_of,
                            first_entry, T.info, T.box, d_prims, d_meta);
         BVH_HIP_OK(hipMemsetAsync(d_nodes, 0, 4 * n_records * sizeof(float4), 0));   // (places of the top that the tree does not fill are copied to LDS with the rest)
-        hipLaunchKernelGGL(ploc_record_places_kernel, dim3(blocks_i), dim3(256), 0, 0, ni, T, record_of);
+        // the four-box records as well (the walk of every frame that does not count its steps), unless a walk could need more
+        // stack than the trace kernel has
+        int4 root_wide = make_int4(0, 0, 0, 0);
+        BVH_HIP_OK(hipMemcpy(&root_wide, T.wide + (ni - 1), sizeof root_wide, hipMemcpyDeviceToHost));   // (the root is the node made last)
+        const bool wide = wide_stack_entries > 0 && !root_info.w && root_wide.z <= wide_stack_entries;
+        float4 *d_wnodes = nullptr;
+        if (wide) {
+            d_wnodes = mem.get<float4>(4 * ((size_t)TOP_RECORDS + (size_t)root_wide.x));
+            if (!d_wnodes) {
+                err = "rt_scene_create: out of device memory for the tree build";
+                return 10;
+            }
+            BVH_HIP_OK(hipMemsetAsync(d_wnodes, 0, 4 * ((size_t)TOP_RECORDS + (size_t)root_wide.x) * sizeof(float4), 0));
+            BVH_HIP_OK(hipMemsetAsync(wide_top, 0xff, (size_t)ni * sizeof(int), 0));
+            BVH_HIP_OK(hipMemsetAsync(wide_words, 0, 2 * sizeof(int), 0));
+            hipLaunchKernelGGL(wide_top_kernel, dim3(1), dim3(64), 0, 0, ni - 1, T, wide_top, wide_queue, wide_words);
+        }
+        hipLaunchKernelGGL(ploc_record_places_kernel, dim3(blocks_i), dim3(256), 0, 0, ni, T, (const int *)wide_top, record_of, wide ? wide_record_of : (int *)nullptr);
         hipLaunchKernelGGL(ploc_records_kernel, dim3(blocks_i), dim3(256), 0, 0, d_bounds, order, ni, T, place, first_entry, record_of, d_nodes);
+        if (wide)
+            hipLaunchKernelGGL(ploc_wide_records_kernel, dim3(blocks_i), dim3(256), 0, 0, d_bounds, order, ni, T, place, first_entry, (const int *)wide_record_of, d_wnodes,
+                               wide_words + 1);
         BVH_HIP_OK(hipGetLastError());
         if (root_info.w) {   // at most four primitives in all, cheaper as one leaf: the root is that leaf
             out.root_ref = (int)0x80000000u;
@@ -462,11 +696,58 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
             out.n_top = TOP_RECORDS;
             out.root_ref = 0;
             mem.release(d_nodes);
+            if (wide) {
+                int words[2] = {0, 1};
+                BVH_HIP_OK(hipMemcpy(words, wide_words, sizeof words, hipMemcpyDeviceToHost));
+                if (!words[1]) {   // (a record that could not be made leaves the scene on the two-box records)
+                    out.wide_nodes = d_wnodes;
+                    out.n_wide = TOP_RECORDS + root_wide.x;
+                    out.n_wide_top = words[0];
+                    mem.release(d_wnodes);
+                }
+            }
         }
     }
     BVH_HIP_OK(hipDeviceSynchronize());
+    clock.mark("entries and records written");
     out.prims = d_prims;
     out.prim_meta = d_meta;
+    mem.release(d_prims);
+    mem.release(d_meta);
+    return 0;
+}
+
+int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
+                         int n_triangles, const rt_instance *d_instances, float id_scale, DeviceBvh &out, std::string &err) {
+    out = DeviceBvh();
+    Scratch mem;
+    rt_bvh_node *d_nodes_in = mem.get<rt_bvh_node>((size_t)n_nodes);
+    int *d_record_of = mem.get<int>((size_t)n_nodes);
+    rt_bvh_prim *d_in = mem.get<rt_bvh_prim>((size_t)n);
+    float4 *d_records = mem.get<float4>(4 * (size_t)n_records), *d_prims = mem.get<float4>(PRIM_STRIDE * (size_t)n);
+    int4 *d_meta = mem.get<int4>(2 * (size_t)n);
+    if (!d_nodes_in || !d_record_of || !d_in || !d_records || !d_prims || !d_meta) {
+        err = "rt_scene_create: out of device memory for the tree's records";
+        return 10;
+    }
+    if (n_nodes > 0) {
+        BVH_HIP_OK(hipMemcpy(d_nodes_in, nodes, (size_t)n_nodes * sizeof(rt_bvh_node), hipMemcpyHostToDevice));
+        BVH_HIP_OK(hipMemcpy(d_record_of, record_of, (size_t)n_nodes * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (n > 0) BVH_HIP_OK(hipMemcpy(d_in, prims, (size_t)n * sizeof(rt_bvh_prim), hipMemcpyHostToDevice));
+    if (n > 0)
+        hipLaunchKernelGGL(entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, (const float *)nullptr, (const unsigned *)nullptr, n, d_triangles, n_triangles,
+                           d_instances, id_scale, (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, (const int4 *)nullptr, (const float *)nullptr, d_prims, d_meta);
+    if (n_nodes > 0) {
+        const unsigned blocks = (unsigned)((n_nodes + 255) / 256);
+        hipLaunchKernelGGL(leaf_boxes_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes_in, n_nodes, d_prims);
+        if (n_records > 0) hipLaunchKernelGGL(node_records_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes_in, n_nodes, d_record_of, d_records);
+    }
+    BVH_HIP_OK(hipGetLastError());
+    BVH_HIP_OK(hipDeviceSynchronize());
+    out.nodes = d_records, out.prims = d_prims, out.prim_meta = d_meta;
+    out.n_interior = n_records;
+    mem.release(d_records);
     mem.release(d_prims);
     mem.release(d_meta);
     return 0;

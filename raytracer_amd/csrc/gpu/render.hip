@@ -30,6 +30,7 @@
 #include "rt_device.h"
 #include "rt_wide.h"
 #include "rt_bvh_gpu.h"
+#include "rt_devmem.h"
 
 using namespace rt;
 
@@ -1385,11 +1386,21 @@ __global__ void math_probe_kernel(int fn, int n, const float *__restrict__ a, co
     out[i] = r;
 }
 
+// A scene's buffers come from the device's block cache (rt_devmem.h) and go back to it in rt_scene_destroy.
 template <class T> int upload(const T *src, size_t n, T **dst) {
-    *dst = nullptr;
-    if (n == 0) n = 1;   // keep pointers valid for empty arrays
-    HIP_OK(hipMalloc((void **)dst, n * sizeof(T)));
-    if (src) HIP_OK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (T *)device_blocks().alloc(std::max<size_t>(n, 1) * sizeof(T));   // (pointers stay valid for empty arrays)
+    if (!*dst) {
+        g_error = "out of device memory for the scene";
+        return 10;
+    }
+    if (src && n > 0) {
+        if (hipError_t e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice); e != hipSuccess) {
+            g_error = std::string("hipMemcpy: ") + hipGetErrorString(e);
+            device_blocks().free(*dst);
+            *dst = nullptr;
+            return 10;
+        }
+    }
     return 0;
 }
 
@@ -1555,39 +1566,55 @@ static int allocate_wavefront(rt_scene *s, unsigned cap, unsigned shadow_mult, i
     return 0;
 }
 
-// One idle wavefront state per device is kept when a scene is destroyed and handed to the next scene created on
-// that device: a sequence of frames (one scene per file) would otherwise allocate and free gigabytes per frame, and
-// the driver answers that with occasional stalls of seconds.
+// Idle wavefront states are kept when a scene is destroyed -- up to IDLE_WAVEFRONTS per device, as many as scenes may be alive
+// on it at once in a sequence of frames (one scene per file, a few render threads) -- and handed to the next scenes created
+// on that device: such a sequence would otherwise allocate and free gigabytes per frame, and the driver answers that with
+// occasional stalls of seconds.
 struct IdleWavefront {
     Wavefront wf{};
     std::vector<void *> allocations;
 };
+constexpr size_t IDLE_WAVEFRONTS = 4;
+constexpr unsigned long long IDLE_WAVEFRONT_BYTES = 32ull << 30;   // what several parked states may hold together (one alone may be larger)
 std::mutex g_idle_mutex;
-std::map<int, IdleWavefront> g_idle_wavefronts;
+std::map<int, std::vector<IdleWavefront>> g_idle_wavefronts;
 
-static void adopt_idle_wavefront(rt_scene *s) {
+static void adopt_idle_wavefront(rt_scene *s) {   // the largest one parked on the scene's device
     std::lock_guard<std::mutex> lk(g_idle_mutex);
     auto it = g_idle_wavefronts.find(s->device);
-    if (it == g_idle_wavefronts.end()) return;
-    s->wf = it->second.wf;
-    s->wf_allocations = std::move(it->second.allocations);
-    g_idle_wavefronts.erase(it);
+    if (it == g_idle_wavefronts.end() || it->second.empty()) return;
+    std::vector<IdleWavefront> &idle = it->second;
+    size_t best = 0;
+    for (size_t k = 1; k < idle.size(); ++k)
+        if (idle[k].wf.capacity > idle[best].wf.capacity) best = k;
+    s->wf = idle[best].wf;
+    s->wf_allocations = std::move(idle[best].allocations);
+    idle.erase(idle.begin() + (long)best);
 }
 
 // true when the scene's wavefront state was parked (the scene no longer owns it)
 static bool park_wavefront(rt_scene *s) {
     if (!s->wf.capacity) return false;
     std::lock_guard<std::mutex> lk(g_idle_mutex);
-    auto it = g_idle_wavefronts.find(s->device);
-    if (it != g_idle_wavefronts.end()) {
-        if (it->second.wf.capacity >= s->wf.capacity) return false;   // the parked one is at least as large: keep it
-        for (void *p : it->second.allocations) (void)hipFree(p);
-        g_idle_wavefronts.erase(it);
+    std::vector<IdleWavefront> &idle = g_idle_wavefronts[s->device];
+    auto bytes_of = [](const Wavefront &W) {   // (allocate_wavefront's sizes)
+        return (unsigned long long)W.capacity * 348ull + (unsigned long long)W.shadow_shard_entries * N_SHARDS * (W.has_records ? 136ull : 72ull);
+    };
+    unsigned long long parked_bytes = 0;
+    for (const IdleWavefront &w : idle) parked_bytes += bytes_of(w.wf);
+    if (idle.size() >= IDLE_WAVEFRONTS || (!idle.empty() && parked_bytes + bytes_of(s->wf) > IDLE_WAVEFRONT_BYTES)) {
+        // no room: this one takes the place of the smallest, if it is larger
+        size_t least = 0;
+        for (size_t k = 1; k < idle.size(); ++k)
+            if (idle[k].wf.capacity < idle[least].wf.capacity) least = k;
+        if (idle[least].wf.capacity >= s->wf.capacity) return false;
+        for (void *p : idle[least].allocations) (void)hipFree(p);
+        idle.erase(idle.begin() + (long)least);
     }
-    IdleWavefront idle;
-    idle.wf = s->wf;
-    idle.allocations = std::move(s->wf_allocations);
-    g_idle_wavefronts[s->device] = std::move(idle);
+    IdleWavefront parked;
+    parked.wf = s->wf;
+    parked.allocations = std::move(s->wf_allocations);
+    idle.push_back(std::move(parked));
     s->wf = Wavefront{};
     s->wf_allocations.clear();
     return true;
@@ -1672,7 +1699,11 @@ static void launch_trace(rt_scene *s, hipStream_t stream, bool any, unsigned gri
 // end at no surface) holds a triangle, and the spheres in such leaves keep their surface away from the point.  Planes are
 // tested before the tree by every walk.  Conservative: a scene that fails keeps the ordered walk.
 static bool shadow_answers_order_free(const rt_scene_desc *d) {
-    if (!d->bvh_nodes || d->n_bvh_nodes < 1 || !d->bvh_prims) return false;
+    // a scene that comes without a tree (one is built on the device) is judged by its primitives' own boxes: every leaf of
+    // whatever tree is built lies inside the boxes of the primitives it holds
+    const bool by_primitives = (!d->bvh_nodes || d->n_bvh_nodes < 1) && d->bvh_prim_bounds && d->n_bvh_prims > 0;
+    if (!by_primitives && (!d->bvh_nodes || d->n_bvh_nodes < 1)) return false;
+    if (!d->bvh_prims) return false;
     const float eps = std::fabs(d->shadow_ray_epsilon);
     for (int li = 0; li < d->n_lights; ++li) {
         const rt_light &L = d->lights[li];
@@ -1699,39 +1730,69 @@ static bool shadow_answers_order_free(const rt_scene_desc *d) {
         for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
         reach = 4.0f * eps + 1e-4f * reach + 1e-3f;   // epsilon, rounding of the distances, padding of the boxes
         if (!std::isfinite(reach)) return false;
+        auto apart = [&](const float *bmin, const float *bmax) {
+            bool yes = false;
+            for (int a = 0; a < 3; ++a) yes |= bmin[a] > hi[a] + reach || bmax[a] < lo[a] - reach;   // (a box that is not a number is not apart)
+            return yes;
+        };
+        auto keeps_away = [&](const rt_bvh_prim &pr) {   // a primitive whose box comes within reach
+            if (pr.shape < d->n_triangles || !point) return false;
+            // a sphere: distance of the point from its surface, in its own space, brought to the world by the least
+            // stretch of its transform (1 / Frobenius norm of the inverse bounds that from below)
+            const rt_sphere &sp = d->spheres[pr.shape - d->n_triangles];
+            const float *im = sp.inv_model;
+            float q[3], norm2 = 0.f, off2 = 0.f;
+            for (int r = 0; r < 3; ++r) {
+                q[r] = im[4 * r] * lo[0] + im[4 * r + 1] * lo[1] + im[4 * r + 2] * lo[2] + im[4 * r + 3];
+                for (int c = 0; c < 3; ++c) norm2 += im[4 * r + c] * im[4 * r + c];
+                off2 += (q[r] - sp.center[r]) * (q[r] - sp.center[r]);
+            }
+            const float from_surface = std::fabs(std::sqrt(off2) - sp.radius) / std::sqrt(norm2);
+            return from_surface > reach;
+        };
+        if (by_primitives) {
+            // (first a count without branches, which the compiler vectorises: lights mostly hang free of everything)
+            const float lo_x = lo[0] - reach, lo_y = lo[1] - reach, lo_z = lo[2] - reach, hi_x = hi[0] + reach, hi_y = hi[1] + reach, hi_z = hi[2] + reach;
+            const float *b = d->bvh_prim_bounds;
+            int near = 0;
+            for (int i = 0; i < d->n_bvh_prims; ++i, b += 6)
+                near += !((b[0] > hi_x) | (b[1] > hi_y) | (b[2] > hi_z) | (b[3] < lo_x) | (b[4] < lo_y) | (b[5] < lo_z)) ? 1 : 0;
+            if (near == 0) continue;
+            for (int i = 0; i < d->n_bvh_prims; ++i) {
+                const float *bi = d->bvh_prim_bounds + 6 * (size_t)i;
+                if (!apart(bi, bi + 3) && !keeps_away(d->bvh_prims[i])) return false;
+            }
+            continue;
+        }
         std::vector<int> todo{0};
         while (!todo.empty()) {
             const int i = todo.back();
             todo.pop_back();
             const rt_bvh_node &n = d->bvh_nodes[i];
-            bool apart = false;
-            for (int a = 0; a < 3; ++a) apart |= n.bmin[a] > hi[a] + reach || n.bmax[a] < lo[a] - reach;   // (a box that is not a number is not apart)
-            if (apart) continue;
+            if (apart(n.bmin, n.bmax)) continue;
             if (n.n_prims == 0) {
                 todo.push_back(i + 1);
                 todo.push_back(n.offset);
                 continue;
             }
-            for (int k = 0; k < n.n_prims; ++k) {
-                const rt_bvh_prim &pr = d->bvh_prims[n.offset + k];
-                if (pr.shape < d->n_triangles || !point) return false;
-                // a sphere: distance of the point from its surface, in its own space, brought to the world by the least
-                // stretch of its transform (1 / Frobenius norm of the inverse bounds that from below)
-                const rt_sphere &sp = d->spheres[pr.shape - d->n_triangles];
-                const float *im = sp.inv_model;
-                float q[3], norm2 = 0.f, off2 = 0.f;
-                for (int r = 0; r < 3; ++r) {
-                    q[r] = im[4 * r] * lo[0] + im[4 * r + 1] * lo[1] + im[4 * r + 2] * lo[2] + im[4 * r + 3];
-                    for (int c = 0; c < 3; ++c) norm2 += im[4 * r + c] * im[4 * r + c];
-                    off2 += (q[r] - sp.center[r]) * (q[r] - sp.center[r]);
-                }
-                const float from_surface = std::fabs(std::sqrt(off2) - sp.radius) / std::sqrt(norm2);
-                if (!(from_surface > reach)) return false;
-            }
+            for (int k = 0; k < n.n_prims; ++k)
+                if (!keeps_away(d->bvh_prims[n.offset + k])) return false;
         }
     }
     return true;
 }
+
+// RT_CREATE_TIMING: stage times of rt_scene_create and rt_scene_destroy on stderr (diagnostic)
+struct CreateClock {
+    const bool on = getenv("RT_CREATE_TIMING") != nullptr;
+    std::chrono::high_resolution_clock::time_point last = std::chrono::high_resolution_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::high_resolution_clock::now();
+        fprintf(stderr, "[create] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
 
 // Builds and uploads the wide tree from the kept copy of the BVH (which is released either way).  A tree that does not
 // qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
@@ -1745,7 +1806,11 @@ static int build_wide_tree(rt_scene *s) {
     static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
     float4 *dev = nullptr;
     HIP_OK(hipSetDevice(s->device));
-    HIP_OK(hipMalloc((void **)&dev, records.size() * sizeof(WideRecord)));
+    dev = (float4 *)device_blocks().alloc(records.size() * sizeof(WideRecord));
+    if (!dev) {
+        g_error = "out of device memory for the wide tree";
+        return 10;
+    }
     s->allocations.push_back(dev);
     HIP_OK(hipMemcpy(dev, records.data(), records.size() * sizeof(WideRecord), hipMemcpyHostToDevice));
     s->dev.wroot_ref = root_ref;
@@ -1778,6 +1843,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         g_error = "rt_scene_create: ABI version mismatch";
         return 2;
     }
+    CreateClock clock;
     // operand checks: every index the kernels follow must be in range
     for (int i = 0; i < d->n_bvh_prims; ++i) {
         const rt_bvh_prim &p = d->bvh_prims[i];
@@ -1848,6 +1914,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         return 3;
     }
 
+    clock.mark("operand checks");
     const bool build_tree = d->n_bvh_nodes == 0 && d->n_bvh_prims > 0;   // the scene comes without a tree: it is built on the device
     if (build_tree && !d->bvh_prim_bounds) {
         g_error = "rt_scene_create: a scene without BVH nodes needs bvh_prim_bounds";
@@ -1862,67 +1929,43 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     DevScene &D = s->dev;
     auto keep = [&](void *p) { s->allocations.push_back(p); };
 
-    // BVH -> interior-node records holding both child boxes (see DevScene); leaves become references
-    std::vector<float4> nodes;
-    int root_ref = 0;
+    // BVH -> interior-node records holding both child boxes (see DevScene); leaves become references.  The host decides
+    // where every record goes; records and leaf entries are written on the device (records_of_host_tree).
+    // Order of the records: the top of the tree breadth-first (the first TOP_NODES interior nodes a breadth-first
+    // walk meets; the trace kernel keeps them in LDS), then every subtree below depth-first (a node's left child
+    // next to it, a small subtree in a few cache lines).
+    std::vector<int> interior_index(d->n_bvh_nodes, -1);
+    int n_interior = 0, root_ref = 0;
     {
-        // Order of the records: the top of the tree breadth-first (the first TOP_NODES interior nodes a breadth-first
-        // walk meets; the trace kernel keeps them in LDS), then every subtree below depth-first (a node's left child
-        // next to it, a small subtree in a few cache lines).
-        std::vector<int> interior_index(d->n_bvh_nodes, -1);
-        int n_interior = 0;
-        {
-            std::vector<int> walk, below;
-            if (d->n_bvh_nodes > 0 && d->bvh_nodes[0].n_prims == 0) walk.push_back(0);
-            for (size_t at = 0; at < walk.size(); ++at) {
-                const int i = walk[at];
-                if (n_interior >= TOP_NODES) {
-                    below.push_back(i);
-                    continue;
-                }
+        std::vector<int> walk, below;
+        if (d->n_bvh_nodes > 0 && d->bvh_nodes[0].n_prims == 0) walk.push_back(0);
+        for (size_t at = 0; at < walk.size(); ++at) {
+            const int i = walk[at];
+            if (n_interior >= TOP_NODES) {
+                below.push_back(i);
+                continue;
+            }
+            interior_index[i] = n_interior++;
+            const int kids[2] = {i + 1, d->bvh_nodes[i].offset};
+            for (int kid : kids)
+                if (d->bvh_nodes[kid].n_prims == 0) walk.push_back(kid);
+        }
+        s->dev.n_top = n_interior;
+        std::vector<int> stack;
+        for (int root : below) {
+            stack.push_back(root);
+            while (!stack.empty()) {
+                const int i = stack.back();
+                stack.pop_back();
                 interior_index[i] = n_interior++;
-                const int kids[2] = {i + 1, d->bvh_nodes[i].offset};
-                for (int kid : kids)
-                    if (d->bvh_nodes[kid].n_prims == 0) walk.push_back(kid);
-            }
-            s->dev.n_top = n_interior;
-            std::vector<int> stack;
-            for (int root : below) {
-                stack.push_back(root);
-                while (!stack.empty()) {
-                    const int i = stack.back();
-                    stack.pop_back();
-                    interior_index[i] = n_interior++;
-                    const int left = i + 1, right = d->bvh_nodes[i].offset;
-                    if (d->bvh_nodes[right].n_prims == 0) stack.push_back(right);
-                    if (d->bvh_nodes[left].n_prims == 0) stack.push_back(left);
-                }
+                const int left = i + 1, right = d->bvh_nodes[i].offset;
+                if (d->bvh_nodes[right].n_prims == 0) stack.push_back(right);
+                if (d->bvh_nodes[left].n_prims == 0) stack.push_back(left);
             }
         }
-        auto ref_of = [&](int i) -> int {
-            const rt_bvh_node &n = d->bvh_nodes[i];
-            if (n.n_prims == 0) return interior_index[i];
-            return (int)(0x80000000u | (unsigned)n.offset);
-        };
-        nodes.resize((size_t)n_interior * 4);
-        for (int i = 0; i < d->n_bvh_nodes; ++i) {
-            const rt_bvh_node &n = d->bvh_nodes[i];
-            if (n.n_prims != 0) continue;
-            const rt_bvh_node &L = d->bvh_nodes[i + 1], &R = d->bvh_nodes[n.offset];
-            const int lr = ref_of(i + 1), rr = ref_of(n.offset);
-            float fl, fr, fa;
-            memcpy(&fl, &lr, 4);
-            memcpy(&fr, &rr, 4);
-            const int axis_bit = 1 << n.axis;
-            memcpy(&fa, &axis_bit, 4);
-            float4 *o = &nodes[(size_t)interior_index[i] * 4];
-            o[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
-            o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
-            o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
-            o[3] = make_float4(fl, fr, fa, 0.f);
-        }
-        if (d->n_bvh_nodes > 0) root_ref = ref_of(0);
+        if (d->n_bvh_nodes > 0) root_ref = d->bvh_nodes[0].n_prims == 0 ? interior_index[0] : (int)(0x80000000u | (unsigned)d->bvh_nodes[0].offset);
     }
+    clock.mark("places of the node records");
     // the inverse of the identity as this scene's inverse routine makes it (see plain_placement): the first such placement's
     float id_scale = 1.0f;
     for (int i = 0; i < d->n_instances; ++i)
@@ -1930,53 +1973,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             id_scale = d->instances[i].inv_model[0];
             break;
         }
-    // leaf entries -> 3 x float4 (scaled vertices and edges as the reference derives them, src/shapes.cpp:22-29,236-237)
-    const int n_host_entries = build_tree ? 0 : d->n_bvh_prims;   // (a tree built on the device makes its entries there)
-    std::vector<float4> prims((size_t)n_host_entries * PRIM_STRIDE);
-    std::vector<int4> prim_meta((size_t)n_host_entries * 2, make_int4(0, 0, 0, 0));
     auto as_float = [](int v) {
         float f;
         memcpy(&f, &v, 4);
         return f;
     };
-    for (int i = 0; i < n_host_entries; ++i) {
-        const rt_bvh_prim &p = d->bvh_prims[i];
-        if (p.shape < d->n_triangles) {
-            const rt_triangle &t = d->triangles[p.shape];
-            float c1s[3], e1[3], e2[3];
-            for (int a = 0; a < 3; ++a) {
-                c1s[a] = t.c1[a] * 1000.0f;
-                e1[a] = t.c2[a] * 1000.0f - c1s[a];
-                e2[a] = t.c3[a] * 1000.0f - c1s[a];
-            }
-            prims[PRIM_STRIDE * i] = make_float4(c1s[0], c1s[1], c1s[2], e1[0]);
-            prims[PRIM_STRIDE * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
-            const rt_instance &in = d->instances[p.instance];
-            const bool plain = plain_placement(in, id_scale);
-            prim_meta[2 * (size_t)i] = make_int4(p.instance | (plain ? 0 : PRIM_XFORM_BIT), p.shape, in.ref_id, t.smooth ? 1 : 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(e2[2], as_float(p.instance | (plain ? 0 : PRIM_XFORM_BIT)), 0.f, 0.f);
-        } else {
-            prims[PRIM_STRIDE * i] = make_float4(0, 0, 0, 0);
-            prims[PRIM_STRIDE * i + 1] = make_float4(0, 0, 0, 0);
-            prim_meta[2 * (size_t)i] = make_int4(-1 - (p.shape - d->n_triangles), p.shape, 123456, 0);
-            prims[PRIM_STRIDE * i + 2] = make_float4(0, as_float((int)(0x80000000u | (unsigned)(p.shape - d->n_triangles))), 0.f, 0.f);
-        }
-        prims[PRIM_STRIDE * i + 3] = make_float4(0, 0, 0, 0);
-    }
-    for (int i = 0; i < d->n_bvh_nodes; ++i) {   // every entry carries the box of its leaf, the last one says that it is
-        const rt_bvh_node &n = d->bvh_nodes[i];
-        for (int k = 0; k < n.n_prims; ++k) {
-            float4 *e = &prims[PRIM_STRIDE * (size_t)(n.offset + k)];
-            e[2].z = n.bmin[0], e[2].w = n.bmin[1];
-            e[3] = make_float4(n.bmin[2], n.bmax[0], n.bmax[1], n.bmax[2]);
-            if (k == n.n_prims - 1) {
-                int word;
-                memcpy(&word, &e[2].y, 4);
-                word |= PRIM_LAST_BIT;
-                memcpy(&e[2].y, &word, 4);
-            }
-        }
-    }
     std::vector<float4> inst((size_t)d->n_instances * 4);
     for (int i = 0; i < d->n_instances; ++i) {
         const rt_instance &in = d->instances[i];
@@ -1984,30 +1985,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         for (int r = 0; r < 3; ++r) inst[4 * i + r] = make_float4(in.inv_model[4 * r], in.inv_model[4 * r + 1], in.inv_model[4 * r + 2], in.inv_model[4 * r + 3]);
         inst[4 * i + 3] = make_float4(in.motionblur[0], in.motionblur[1], in.motionblur[2], as_float(flags));
     }
-    // flat normals: normalize(cross(e1s, e2s)) (src/shapes.cpp:26-33), evaluated in the same order as on the device
-    std::vector<float> flat(build_tree ? 0 : (size_t)d->n_triangles * 3);
-    for (int i = 0; i < d->n_triangles && !build_tree; ++i) {
-        const rt_triangle &t = d->triangles[i];
-        float e1[3], e2[3];
-        for (int a = 0; a < 3; ++a) {
-            float c1s = t.c1[a] * 1000.0f;
-            e1[a] = t.c2[a] * 1000.0f - c1s;
-            e2[a] = t.c3[a] * 1000.0f - c1s;
-        }
-        float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        float len2 = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
-        float inv = len2 > 1e-12f ? 1.0f / sqrtf(len2) : 0.0f;
-        for (int a = 0; a < 3; ++a) flat[3 * i + a] = len2 > 1e-12f ? n[a] * inv : 0.0f;
-    }
-
-    for (int i = 0; i < n_host_entries; ++i) {   // the face normal travels with the entry's shading record
-        const rt_bvh_prim &p = d->bvh_prims[i];
-        if (p.shape >= d->n_triangles) continue;
-        int bits[3];
-        memcpy(bits, &flat[3 * (size_t)p.shape], sizeof bits);
-        prim_meta[2 * (size_t)i + 1] = make_int4(bits[0], bits[1], bits[2], 0);
-    }
-
 #define UP(field, vec_ptr, count)                                                     \
     do {                                                                              \
         decltype(D.field) dp_ = nullptr;                                              \
@@ -2021,35 +1998,45 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         D.field = dp_;                                                                \
         keep(tmp_);                                                                   \
     } while (0)
+    clock.mark("placements");
     UP(inst, inst.data(), inst.size());
     UP(instances, d->instances, d->n_instances);
     UP(triangles, d->triangles, d->n_triangles);
+    clock.mark("placements and triangles uploaded");
     DeviceBvh built;
     if (build_tree) {
-        // the walk's stack holds LDS_STACK + SPILL_STACK far children, one per level
-        if (int rc = build_bvh_on_device(d->bvh_prims, d->bvh_prim_bounds, d->n_bvh_prims, D.triangles, d->n_triangles, D.instances, id_scale, LDS_STACK + SPILL_STACK - 1, built, g_error)) {
+        // the walk's stack holds LDS_STACK + SPILL_STACK far children, one per level; the four-box records are made with the tree
+        // (RT_WIDE_NODES=0: not at all)
+        const char *wide_mode = getenv("RT_WIDE_NODES");
+        const int wide_stack = wide_mode && atoi(wide_mode) == 0 ? 0 : LDS_STACK + SPILL_STACK;
+        if (int rc = build_bvh_on_device(d->bvh_prims, d->bvh_prim_bounds, d->n_bvh_prims, D.triangles, d->n_triangles, D.instances, id_scale, LDS_STACK + SPILL_STACK - 1, wide_stack,
+                                         built, g_error)) {
             rt_scene_destroy(s);
             return rc;
         }
-        D.nodes = built.nodes, D.prims = built.prims, D.prim_meta = built.prim_meta;
-        for (void *p : {(void *)built.nodes, (void *)built.prims, (void *)built.prim_meta})
-            if (p) keep(p);
-        if (!built.nodes) {   // (pointers stay valid for an empty array, as upload() keeps them)
-            float4 *dummy = nullptr;
-            if (upload<float4>(nullptr, 0, &dummy)) {
-                rt_scene_destroy(s);
-                return 10;
-            }
-            D.nodes = dummy;
-            keep(dummy);
-        }
         root_ref = built.root_ref;
         s->dev.n_top = built.n_top;   // the builder puts the top levels first, as the host's layout does
-    } else {
-        UP(nodes, nodes.data(), nodes.size());
-        UP(prims, prims.data(), prims.size());
-        UP(prim_meta, prim_meta.data(), prim_meta.size());
+    } else if (int rc = records_of_host_tree(d->bvh_nodes, d->n_bvh_nodes, interior_index.data(), n_interior, d->bvh_prims, d->n_bvh_prims, D.triangles, d->n_triangles,
+                                             D.instances, id_scale, built, g_error)) {
+        rt_scene_destroy(s);
+        return rc;
     }
+    D.nodes = built.nodes, D.prims = built.prims, D.prim_meta = built.prim_meta;
+    for (void *p : {(void *)built.nodes, (void *)built.prims, (void *)built.prim_meta, (void *)built.wide_nodes})
+        if (p) keep(p);
+    if (built.wide_nodes) D.wnodes = built.wide_nodes, D.wroot_ref = 0, D.n_wtop = built.n_wide_top;
+    if (!built.nodes || !built.prims || !built.prim_meta) {   // (pointers stay valid for an empty array, as upload() keeps them)
+        float4 *dummy = nullptr;
+        if (upload<float4>(nullptr, 0, &dummy)) {
+            rt_scene_destroy(s);
+            return 10;
+        }
+        keep(dummy);
+        if (!D.nodes) D.nodes = dummy;
+        if (!D.prims) D.prims = dummy;
+        if (!D.prim_meta) D.prim_meta = (const int4 *)dummy;
+    }
+    clock.mark("tree");
     UP(spheres, d->spheres, d->n_spheres);
     UP(planes, d->planes, d->n_planes);
     UP(materials, d->materials, d->n_materials);
@@ -2060,6 +2047,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     UP(texels_f32, d->texels_f32, d->n_texels_f32);
     UP(lights, d->lights, d->n_lights);
 #undef UP
+    clock.mark("materials, textures, lights uploaded");
     D.n_triangles = d->n_triangles;
     D.n_spheres = d->n_spheres;
     D.n_planes = d->n_planes;
@@ -2091,7 +2079,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.bg, d->background_color, sizeof D.bg);
     D.bg_tex = d->background_texture;
     D.is_probe = d->is_probe;
-    if (hipMalloc((void **)&s->stats, 2 * STAT_ROWS * STAT_WORDS * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+    if (!(s->stats = (unsigned long long *)device_blocks().alloc(2 * STAT_ROWS * STAT_WORDS * sizeof(unsigned long long))) || hipStreamCreate(&s->stream) != hipSuccess ||
         hipStreamCreate(&s->stream2) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         g_error = "rt_scene_create: cannot allocate stream/events";
@@ -2150,23 +2138,26 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         s->plain_shading = s->only_regular_materials && d->n_textures == 0 && !(getenv("RT_PLAIN_SHADING") && atoi(getenv("RT_PLAIN_SHADING")) == 0);
         s->shadow_order_free = !(getenv("RT_ANY_ORDERED") && atoi(getenv("RT_ANY_ORDERED")) != 0) && shadow_answers_order_free(d);
     }
+    clock.mark("streams, light tables, decisions about the scene");
     *out = s;
     return 0;
 }
 
 void rt_scene_destroy(rt_scene *s) {
     if (!s) return;
+    CreateClock clock;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     (void)hipSetDevice(s->device);
     drop_frame_graph(s);
     park_wavefront(s);
-    for (void *p : s->allocations) (void)hipFree(p);
+    clock.mark("destroy: streams, graph, wavefront parked");
+    for (void *p : s->allocations) device_blocks().free(p);
     for (void *p : s->wf_allocations) (void)hipFree(p);
     if (s->host_flags) (void)hipHostFree(s->host_flags);
-    if (s->stats) (void)hipFree(s->stats);
-    if (s->framebuffer) (void)hipFree(s->framebuffer);
-    if (s->owned_tiles) (void)hipFree(s->owned_tiles);
+    device_blocks().free(s->stats);
+    device_blocks().free(s->framebuffer);
+    device_blocks().free(s->owned_tiles);
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->shaded) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->lit) (void)hipEventDestroy(e);
@@ -2174,6 +2165,7 @@ void rt_scene_destroy(rt_scene *s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    clock.mark("destroy: buffers, events, streams released");
     delete s;
 }
 
@@ -2239,10 +2231,13 @@ static int ensure_owned_tiles(rt_scene *s, int resx, int resy, int rank, int wor
             if (shard_owner(tx, ty, world) == rank) list.push_back(ty * tiles_x + tx);
     if (list.size() + 1 > s->owned_room) {
         HIP_OK(hipStreamSynchronize(s->stream));
-        if (s->owned_tiles) (void)hipFree(s->owned_tiles);
+        device_blocks().free(s->owned_tiles);
         s->owned_tiles = nullptr;
         s->owned_room = 0;
-        HIP_OK(hipMalloc((void **)&s->owned_tiles, (list.size() + 1) * sizeof(int)));
+        if (!(s->owned_tiles = (int *)device_blocks().alloc((list.size() + 1) * sizeof(int)))) {
+            g_error = "out of device memory for the tile list";
+            return 10;
+        }
         s->owned_room = list.size() + 1;
     }
     if (!list.empty()) HIP_OK(hipMemcpy(s->owned_tiles, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -2610,10 +2605,13 @@ static int scene_buffer(rt_scene *s, float *&buf, size_t &room, size_t n_floats)
     if (room >= n_floats && buf) return 0;
     HIP_OK(hipSetDevice(s->device));
     HIP_OK(hipStreamSynchronize(s->stream));
-    if (buf) (void)hipFree(buf);
+    device_blocks().free(buf);
     buf = nullptr;
     room = 0;
-    HIP_OK(hipMalloc((void **)&buf, std::max<size_t>(n_floats, 1) * sizeof(float)));
+    if (!(buf = (float *)device_blocks().alloc(std::max<size_t>(n_floats, 1) * sizeof(float)))) {
+        g_error = "out of device memory for the frame";
+        return 10;
+    }
     room = n_floats;
     return 0;
 }
@@ -2661,6 +2659,7 @@ int32_t rt_queue_shard_of(uint32_t group_of_sample, uint32_t sample) { return qu
 uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { return max_shard_groups(groups_per_sample, samples); }
 int32_t rt_scene_shadow_order_free(const rt_scene *s) { return s && s->shadow_order_free ? 1 : 0; }
 int32_t rt_scene_plain_shading(const rt_scene *s) { return s && s->plain_shading ? 1 : 0; }
+int32_t rt_scene_wide_records(const rt_scene *s) { return s && s->dev.wnodes ? 1 : 0; }
 int32_t rt_shadow_order_free(const rt_scene_desc *d) { return d && d->abi_version == RT_ABI_VERSION && shadow_answers_order_free(d) ? 1 : 0; }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major

@@ -14,15 +14,25 @@ struct DeviceBvh {
     int4 *prim_meta = nullptr;    // shading records (DevScene::prim_meta)
     int n_interior = 0;
     int n_top = 0;                // the first n_top records are the top levels of the tree, level by level (DevScene::n_top)
+    float4 *wide_nodes = nullptr; // four-box records (DevScene::wnodes), record 0 heads the root; nullptr when the tree has none
+    int n_wide = 0;               // records allocated (places the tree does not use are zero)
+    int n_wide_top = 0;           // the first n_wide_top of them are the top of the tree, breadth-first (DevScene::n_wtop)
     int root_ref = 0;
     int depth = 0;                // interior nodes on the longest root-to-leaf path
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 };
 
 // Builds the tree over `n` (shape, placement) pairs with world-space boxes `bounds` (6 floats each: min, max), both in
-// host memory; triangles and instances are the scene's arrays already on the device; `id_scale`: DevScene::id_scale.  Returns 0 and the device arrays
-// (owned by the caller, hipFree), or an error code with a message.
+// host memory; triangles and instances are the scene's arrays already on the device; `id_scale`: DevScene::id_scale;
+// `wide_stack_entries`: the stack a walk of the four-box records has (0: do not make them).  Returns 0 and the device arrays
+// (owned by the caller; they come from device_blocks() of rt_devmem.h and go back to it), or an error code with a message.
 int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, const rt_triangle *d_triangles, int n_triangles,
-                        const rt_instance *d_instances, float id_scale, int max_depth, DeviceBvh &out, std::string &err);
+                        const rt_instance *d_instances, float id_scale, int max_depth, int wide_stack_entries, DeviceBvh &out, std::string &err);
+
+// The records of a tree that came with the scene, made on the device from the reference's node array (src/bvh.h:9-28; nodes,
+// record_of and prims in host memory): `record_of[i]` is where interior node i's two-box record goes (n_records places in
+// all), leaf entries keep the order of `prims`.  Fills out.nodes, out.prims, out.prim_meta (owned by the caller, as above).
+int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
+                         int n_triangles, const rt_instance *d_instances, float id_scale, DeviceBvh &out, std::string &err);
 
 }  // namespace rt

@@ -149,6 +149,32 @@ static void job_printf(FileJob &job, const char *fmt, ...) {
 struct Team {
     std::vector<int> devices;
     std::vector<rt_comm *> comms;   // one per device when the team has more than one
+    // on devices[0], kept from frame to frame (grown when a frame needs more): the float frame a PNG is made from, and its
+    // 8-bit pixels before they cross to the host
+    float *frame = nullptr;
+    size_t frame_values = 0;
+    uint8_t *ldr = nullptr;
+    size_t ldr_bytes = 0;
+    bool room_for(size_t n_values) {   // both buffers hold a frame of n_values floats; false when the device is out of memory
+        if (frame_values < n_values) {
+            if (frame) (void)hipFree(frame);
+            frame = nullptr, frame_values = 0;
+            if (hipMalloc((void **)&frame, n_values * sizeof(float)) != hipSuccess) return false;
+            frame_values = n_values;
+        }
+        if (ldr_bytes < n_values) {
+            if (ldr) (void)hipFree(ldr);
+            ldr = nullptr, ldr_bytes = 0;
+            if (hipMalloc((void **)&ldr, n_values) != hipSuccess) return false;
+            ldr_bytes = n_values;
+        }
+        return true;
+    }
+    void release_buffers() {
+        if (frame) (void)hipFree(frame);
+        if (ldr) (void)hipFree(ldr);
+        frame = nullptr, ldr = nullptr, frame_values = ldr_bytes = 0;
+    }
 };
 
 // `gpus` cut into teams of `size` (the last one takes what is left).
@@ -294,6 +320,12 @@ private:
 
     // ---- stage 2: one thread per team of GPUs, scenes in file order ---------------------------------------------
     void render_loop(Team &team) {
+        struct Release {   // the team's frame buffers go when its thread ends
+            Team &t;
+            ~Release() {
+                if (!t.devices.empty() && hipSetDevice(t.devices[0]) == hipSuccess) t.release_buffers();
+            }
+        } release{team};
         for (;;) {
             size_t i;
             const auto t_wait = std::chrono::high_resolution_clock::now();
@@ -435,17 +467,20 @@ private:
             // Only an EXR needs the float frame on the host; for PNG outputs the frame stays in HBM and is tone-mapped
             // or quantised there (rt_tonemap / rt_quantize_ldr), so 8-bit pixels are all that crosses PCIe.
             WriteTask exr_task{WriteTask::EXR_RGB32F, "outputs/" + name, W, H, {}, {}};
-            float *frame = nullptr, *device_frame = nullptr;
+            float *frame = nullptr;
             if (exr) {
                 exr_task.rgb32f.assign(n_values, 0.0f);
                 frame = exr_task.rgb32f.data();
             } else {
-                if (hipMalloc((void **)&device_frame, n_values * sizeof(float)) != hipSuccess) {
+                if (!crew.room_for(n_values)) {
                     job_printf(job, "cannot allocate the device framebuffer\n");
                     fail(index, -1);
                 }
-                frame = device_frame;
+                frame = crew.frame;
             }
+            // 8-bit pixels are made in the team's device buffer and copied out (an EXR frame is on the host: the library stages it)
+            auto to_host = [&](std::vector<uint8_t> &pixels) { return exr || hipMemcpy(pixels.data(), crew.ldr, n_values, hipMemcpyDeviceToHost) == hipSuccess; };
+            uint8_t *const ldr_out_dev = exr ? nullptr : crew.ldr;
             rt_stats stats;
             if (n_ranks == 1) {
                 if (rt_render(gpu, &cam.desc, frame, &stats) != 0) {
@@ -485,7 +520,7 @@ private:
             std::vector<WriteTask> tasks;
             if (!exr && cam.tonemaps.empty()) {
                 WriteTask t{WriteTask::PNG_RGB8, "outputs/" + name, W, H, std::vector<uint8_t>(n_values), {}};
-                if (rt_quantize_ldr(frame, (int64_t)n_values, t.rgb8.data()) != 0) {
+                if (rt_quantize_ldr(frame, (int64_t)n_values, ldr_out_dev ? ldr_out_dev : t.rgb8.data()) != 0 || !to_host(t.rgb8)) {
                     job_printf(job, "rt_quantize_ldr failed: %s\n", rt_last_error());
                     fail(index, -1);
                 }
@@ -497,7 +532,7 @@ private:
                 if (dot != std::string::npos) base = base.substr(0, dot);
                 WriteTask t{WriteTask::PNG_RGB8, "outputs/" + base + tm.extension, W, H, std::vector<uint8_t>(n_values), {}};
                 const rt_tonemap_desc td{tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma};
-                if (rt_tonemap(frame, W, H, &td, t.rgb8.data()) != 0) {
+                if (rt_tonemap(frame, W, H, &td, ldr_out_dev ? ldr_out_dev : t.rgb8.data()) != 0 || !to_host(t.rgb8)) {
                     job_printf(job, "rt_tonemap failed: %s\n", rt_last_error());
                     fail(index, -1);
                 }
@@ -511,7 +546,6 @@ private:
                 if (!cam.tonemaps.empty()) job_printf(job, "Saving tone mapped image: %s\n", t.path.substr(strlen("outputs/")).c_str());
                 submit(std::move(t));
             }
-            if (device_frame) (void)hipFree(device_frame);
             if (timing) job_printf(job, "[timing] camera total %.1f ms (render + tone map + hand-off)\n", since(start));
         }
         auto t_destroy = std::chrono::high_resolution_clock::now();

@@ -1,5 +1,6 @@
 """The tree built on the device (a scene loaded with RT_GPU_BVH=1 carries no tree; rt_scene_create builds one: Morton
-order, one leaf per primitive) against the reference's SAH tree built on the host, for the same scene.
+order, clusters merged bottom-up, leaves of up to four primitives, two-box and four-box records) against the reference's
+SAH tree built on the host, for the same scene.
 
 The two trees hold the same primitives in different shapes, so rays meet them in a different order.  What must agree:
 hit or miss for every primary ray; the hit distance; and the primitive, except where two primitives are hit at exactly
@@ -29,12 +30,19 @@ def two_scenes(path, monkeypatch):
     return host_tree, no_tree
 
 
+@pytest.mark.parametrize("walk", ["four_box", "two_box"])
 @pytest.mark.parametrize("name", ["simple", "mesh70k"] + sorted(GS.SCENES))
-def test_device_tree_finds_the_same_hits(name, scene_dir, repo_root, monkeypatch):
+def test_device_tree_finds_the_same_hits(name, walk, scene_dir, repo_root, monkeypatch):
+    """Both sets of records the builder writes: the four-box records every uncounted frame walks, and (RT_WIDE_NODES=0, or
+    with the work counters on) the two-box records."""
+    if walk == "two_box":
+        monkeypatch.setenv("RT_WIDE_NODES", "0")
     host_tree, no_tree = two_scenes(scene_path(name, scene_dir, repo_root), monkeypatch)
     cam = host_tree.camera(0)
     s0, i0, t0, _ = Oracle(host_tree).trace_primary(cam)              # the reference's tree, walked on the host
     ren = R.Renderer(no_tree)
+    if walk == "two_box" or no_tree.desc.n_bvh_prims > 4:             # (a tree of up to four primitives may be a single leaf)
+        assert ren.wide_records() == (walk == "four_box")
     s1, i1, t1, _ = ren.trace_primary(cam)
     assert np.array_equal(s0 >= 0, s1 >= 0), "hit / miss differs"
     assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32)), "closest distances differ"

@@ -248,22 +248,27 @@ def test_write_outputs_follows_the_reference(tmp_path):
     assert [os.path.basename(p) for p in R.write_outputs(sc2, 0, img2, out_dir=str(tmp_path / "o"))] == ["simple.png"]
 
 
-def test_shadow_ray_order_decision_on_the_host(tmp_path):
+@pytest.mark.parametrize("tree", ["from_the_host", "none"])
+def test_shadow_ray_order_decision_on_the_host(tree, tmp_path, monkeypatch):
     """rt_shadow_order_free (host only): shadow rays may be walked in any order exactly when no surface can lie within the
     shadow-ray epsilon of a light sample (such a hit ends a shadow ray without counting as shadow, src/ray_trace.cpp:232-241,
     so only then does the order of the walk matter).  Lights that hang free of the geometry: yes; emitters made of triangles
-    and a point light moved onto a vertex of a mesh: no."""
+    and a point light moved onto a vertex of a mesh: no.  A scene that comes without a tree (RT_GPU_BVH=1: one is built on
+    the device) is judged by its primitives' boxes, with the same answers."""
     import ctypes as C
     import json
     import os
     import raytracer_amd as R
     from raytracer_amd import scenegen
     from golden import scenes as GS
+    if tree == "none":
+        monkeypatch.setenv("RT_GPU_BVH", "1")
     g = R.gpu_lib()
     g.rt_shadow_order_free.restype = C.c_int32
     g.rt_shadow_order_free.argtypes = [C.c_void_p]
     def free(path):
         sc = R.Scene(path)
+        assert (sc.desc.n_bvh_nodes == 0) == (tree == "none")
         return bool(g.rt_shadow_order_free(C.byref(sc.desc)))
     out = str(tmp_path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -18,9 +18,16 @@ for k in range(n):
     json.dump(doc, open(os.path.join(frames, f"anim_{k:04d}.json"), "w"))
 runs = [("this repository", os.path.join(ROOT, "raytracer"), {}),
         ("this repository, trees built on the device (RT_GPU_BVH=1)", os.path.join(ROOT, "raytracer"), {"RT_GPU_BVH": "1"}),
+        ("this repository, trees built on the device, two-box records only (RT_GPU_BVH=1 RT_WIDE_NODES=0)", os.path.join(ROOT, "raytracer"),
+         {"RT_GPU_BVH": "1", "RT_WIDE_NODES": "0"}),
         ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"), {})]
 if "--no-reference" in sys.argv:
     runs.pop()
+if "--against-old" in sys.argv:   # A/B on one box: a build of an earlier commit under ab_old/ (tools: see DESIGN), three runs each in turn
+    old = os.path.join(ROOT, "ab_old", "raytracer")
+    runs = [(f"{label} [{which}, run {r}]", exe if which == "new" else old, env) for r in range(3) for label, exe, env in runs[:2] for which in ("old", "new")]
+if "--render-threads" in sys.argv:   # several render threads on the one GPU (RT_GPUS_DEVICES names it more than once)
+    runs = [(f"{label}, {k} render threads on the GPU", exe, dict(env, RT_GPUS_DEVICES=",".join(["0"] * k))) for label, exe, env in runs[:2] for k in (1, 2, 3, 4)]
 for k, (label, exe, env) in enumerate(runs):
     if not os.path.exists(exe):
         continue
