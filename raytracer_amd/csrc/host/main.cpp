@@ -243,11 +243,19 @@ public:
 
     void run() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        // per render thread (one per GPU) up to four loaders and four writers: a 1080p frame of a light scene takes 4 ms to
-        // render, 4-10 ms to parse and 16 ms to encode as PNG, so eight GPUs need eight times the helpers of one
-        const unsigned per_gpu = 4u * (unsigned)std::max<size_t>(1, teams_.size());
-        const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), std::max(1u, std::min(per_gpu, hw / 4)));
-        const unsigned n_write = std::max(1u, std::min(per_gpu, hw / 4));
+        // per render thread (one per team) up to eight loaders and six writers: a 1080p frame of a light scene keeps its
+        // render thread for 3 ms (scene to the device, render, tone map), takes 20 ms to parse and build its tree and 15 ms to
+        // encode as PNG, so the helpers of one GPU fill fifteen cores and eight GPUs need eight times as many
+        // (RT_LOADERS / RT_WRITERS: the counts themselves)
+        const unsigned n_teams = (unsigned)std::max<size_t>(1, teams_.size());
+        auto wanted = [&](const char *name, unsigned per_team) {
+            const char *e = getenv(name);
+            const unsigned n = e && atoi(e) > 0 ? (unsigned)atoi(e) : std::min(per_team * n_teams, std::max(1u, hw / 2));
+            return std::max(1u, std::min(n, 256u));
+        };
+        const unsigned n_load = (unsigned)std::min<size_t>(jobs_.size(), wanted("RT_LOADERS", 8));
+        const unsigned n_write = wanted("RT_WRITERS", 6);
+        load_ahead_ = std::max<size_t>(2 * teams_.size() + 2, n_load + teams_.size());
         std::vector<std::thread> loaders, renderers, writers;
         for (unsigned i = 0; i < n_load; ++i) loaders.emplace_back([this] { load_loop(); });
         for (unsigned i = 0; i < n_write; ++i) writers.emplace_back([this] { write_loop(); });
@@ -279,16 +287,20 @@ public:
     }
 
 private:
-    // ---- stage 1: parse + BVH build, at most `ahead` files beyond the one being rendered ----------------------
+    // ---- stage 1: parse + BVH build, at most load_ahead_ files beyond the last one reported -------------------
     void load_loop() {
         for (;;) {
             size_t i;
             {
+                std::vector<rth::HostScene> spent;   // scenes the render threads are done with: released here, outside the lock
                 std::unique_lock<std::mutex> lk(m_);
+                spent.swap(spent_scenes_);
+                lk.unlock();
+                spent.clear();
+                lk.lock();
                 i = next_load_++;
                 if (i >= jobs_.size()) return;
-                const size_t ahead = 2 * teams_.size() + 2;
-                cv_.wait(lk, [&] { return i < flushed_ + ahead; });
+                cv_.wait(lk, [&] { return i < flushed_ + load_ahead_; });   // bounds the scenes held in host memory
             }
             FileJob &job = jobs_[i];
             static const char *names[] = {"row_dynamic", "row_static", "square_dynamic", "pixel_dynamic"};
@@ -348,10 +360,12 @@ private:
             if (!job.scene.cameras.empty() && (thread_count_ > 4096 || thread_count_ < 1)) fail(i, -2);
             render_scene(i, job, team);
             const auto t_tail = std::chrono::high_resolution_clock::now();
-            job.scene = rth::HostScene();   // release the host arrays
+            rth::HostScene spent;           // the host arrays are released by a loader thread (half a millisecond this thread has no time for)
+            std::swap(spent, job.scene);
             const double free_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_tail).count();
             {
                 std::lock_guard<std::mutex> lk(m_);
+                spent_scenes_.push_back(std::move(spent));
                 job.done = true;
                 while (flushed_ < jobs_.size() && jobs_[flushed_].done) {
                     log_printf("%s", jobs_[flushed_].log.c_str());
@@ -557,7 +571,7 @@ private:
     // ---- stage 3: encode and write ---------------------------------------------------------------------------
     void submit(WriteTask &&t) {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return write_queue_.size() < 8; });   // bounds the frames held in host memory
+        cv_.wait(lk, [&] { return write_queue_.size() < 16; });   // bounds the frames held in host memory
         write_queue_.push_back(std::move(t));
         lk.unlock();
         cv_.notify_all();
@@ -607,10 +621,12 @@ private:
     int thread_count_, threading_type_;
     std::vector<int> gpus_;
     std::vector<Team> teams_, tail_teams_;   // who renders the frames in turn, and who renders the frames left over
+    size_t load_ahead_ = 4;                  // files that may be loaded beyond the last one whose log has been printed
     size_t bulk_frames_ = 0;                 // frames handed to teams_; the rest goes to tail_teams_
     size_t render_limit_ = 0;                // frames that may be taken in the current phase
     std::vector<FileJob> jobs_;
     std::vector<WriteTask> write_queue_;
+    std::vector<rth::HostScene> spent_scenes_;
     std::mutex m_;
     std::condition_variable cv_;
     size_t next_load_ = 0, next_render_ = 0, flushed_ = 0, writes_in_flight_ = 0;
