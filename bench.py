@@ -309,11 +309,20 @@ def main():
     gather = "none"
     if world > 1:   # the library's communicator: tiles are rendered per rank and gathered on rank 0 over RCCL
         gather = "packed tiles to rank 0, library RCCL send/recv"
-        try:
-            comm = R.Comm.init_rank(sharding.exchange_unique_id(rank, world), rank, world)
-        except Exception as e:   # said aloud, and in the line: the frames are then summed by torch.distributed instead
-            sys.stderr.write(f"bench.py rank {rank}: library communicator unavailable ({e}); gathering with torch.distributed\n")
-        ok = torch.tensor([1 if comm is not None else 0], device="cuda" if args.backend == "nccl" else "cpu")
+        where = "cuda" if args.backend == "nccl" else "cpu"
+        # making the communicator is a collective of its own (every rank must enter it): first agree that every rank can
+        g = R.gpu_lib()
+        g.rt_comm_available.restype = C.c_int32
+        able = torch.tensor([int(g.rt_comm_available())], device=where)
+        dist.all_reduce(able, op=dist.ReduceOp.MIN)
+        if int(able[0]) == 1:
+            try:
+                comm = R.Comm.init_rank(sharding.exchange_unique_id(rank, world), rank, world)
+            except Exception as e:   # said aloud, and in the line: the frames are then summed by torch.distributed instead
+                sys.stderr.write(f"bench.py rank {rank}: library communicator unavailable ({e}); gathering with torch.distributed\n")
+        elif rank == 0:
+            sys.stderr.write("bench.py: RCCL cannot be opened by the library on every rank; gathering with torch.distributed\n")
+        ok = torch.tensor([1 if comm is not None else 0], device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok[0]) == 0:
             if comm is not None:

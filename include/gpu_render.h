@@ -333,6 +333,10 @@ int rt_shard_layout(int32_t resx, int32_t resy, int32_t world, int32_t *tiles_of
 
 #define RT_COMM_ID_BYTES 128
 typedef struct rt_comm rt_comm;
+/* 1 when the RCCL entry points the communicators need could be opened in this process (no GPU work, no communication):
+ * ranks can agree on this before any of them enters rt_comm_init_rank, which -- like ncclCommInitRank -- returns only when
+ * every rank has made the call. */
+int32_t rt_comm_available(void);
 int rt_comm_unique_id(void *id_out, int32_t id_bytes);
 int rt_comm_init_rank(const void *id, int32_t id_bytes, int32_t rank, int32_t world, rt_comm **out);
 int rt_comm_init_all(int32_t n, const int32_t *devices, rt_comm **comms_out);

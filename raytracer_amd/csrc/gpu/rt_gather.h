@@ -205,6 +205,8 @@ int rt_shard_layout(int32_t resx, int32_t resy, int32_t world, int32_t *tiles_of
     return 0;
 }
 
+int32_t rt_comm_available(void) { return rccl_api() ? 1 : 0; }
+
 int rt_comm_unique_id(void *id_out, int32_t id_bytes) {
     RcclApi *api = rccl_api();
     if (!api) {
