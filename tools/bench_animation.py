@@ -16,9 +16,10 @@ for k in range(n):
     cam["Position"] = f"{3.2 * math.sin(a):.5f} 0.5 {3.2 * math.cos(a):.5f}"
     cam["ImageName"] = f"anim_{k:04d}.png"
     json.dump(doc, open(os.path.join(frames, f"anim_{k:04d}.json"), "w"))
-runs = [("this repository", os.path.join(ROOT, "raytracer"), {}),
-        ("this repository, trees built on the device (RT_GPU_BVH=1)", os.path.join(ROOT, "raytracer"), {"RT_GPU_BVH": "1"}),
-        ("this repository, trees built on the device, two-box records only (RT_GPU_BVH=1 RT_WIDE_NODES=0)", os.path.join(ROOT, "raytracer"),
+EXE = os.environ.get("RT_BENCH_EXE", os.path.join(ROOT, "raytracer"))   # (another build of the command line, for A/B runs)
+runs = [("this repository", EXE, {}),
+        ("this repository, trees built on the device (RT_GPU_BVH=1)", EXE, {"RT_GPU_BVH": "1"}),
+        ("this repository, trees built on the device, two-box records only (RT_GPU_BVH=1 RT_WIDE_NODES=0)", EXE,
          {"RT_GPU_BVH": "1", "RT_WIDE_NODES": "0"}),
         ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"), {})]
 if "--no-reference" in sys.argv:
