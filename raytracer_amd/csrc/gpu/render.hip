@@ -1620,6 +1620,72 @@ static bool park_wavefront(rt_scene *s) {
     return true;
 }
 
+// The two streams and the events of a destroyed scene wait here for the next scene on the same device (up to IDLE_STREAM_SETS a
+// device): making and destroying them was a quarter of a millisecond per scene of a frame sequence.  Everything on the streams
+// has finished when a set is parked.
+struct StreamSet {
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> shaded, lit;
+    unsigned *host_flags = nullptr;   // the pinned word a frame's overflow flag is copied to (rt_scene::host_flags), made on first use
+};
+constexpr size_t IDLE_STREAM_SETS = 8;
+std::mutex g_stream_sets_mutex;
+std::map<int, std::vector<StreamSet>> g_idle_stream_sets;
+
+static void destroy_stream_set(StreamSet &t) {
+    for (hipEvent_t e : t.shaded) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t.lit) (void)hipEventDestroy(e);
+    if (t.stream2) (void)hipStreamDestroy(t.stream2);
+    if (t.ev0) (void)hipEventDestroy(t.ev0);
+    if (t.ev1) (void)hipEventDestroy(t.ev1);
+    if (t.stream) (void)hipStreamDestroy(t.stream);
+    if (t.host_flags) (void)hipHostFree(t.host_flags);
+    t = StreamSet();
+}
+
+// A parked set of the current scene's device, or a new one; false when the runtime cannot make one.
+static bool take_stream_set(rt_scene *s) {
+    StreamSet t;
+    {
+        std::lock_guard<std::mutex> lk(g_stream_sets_mutex);
+        std::vector<StreamSet> &idle = g_idle_stream_sets[s->device];
+        if (!idle.empty()) {
+            t = std::move(idle.back());
+            idle.pop_back();
+        }
+    }
+    if (!t.stream && (hipStreamCreate(&t.stream) != hipSuccess || hipStreamCreate(&t.stream2) != hipSuccess || hipEventCreate(&t.ev0) != hipSuccess ||
+                      hipEventCreate(&t.ev1) != hipSuccess)) {
+        destroy_stream_set(t);
+        return false;
+    }
+    s->stream = t.stream, s->stream2 = t.stream2, s->ev0 = t.ev0, s->ev1 = t.ev1;
+    s->shaded = std::move(t.shaded), s->lit = std::move(t.lit);
+    s->host_flags = t.host_flags;
+    return true;
+}
+
+static void park_stream_set(rt_scene *s) {   // (the scene's streams are idle)
+    StreamSet t;
+    t.stream = s->stream, t.stream2 = s->stream2, t.ev0 = s->ev0, t.ev1 = s->ev1;
+    t.shaded = std::move(s->shaded), t.lit = std::move(s->lit);
+    t.host_flags = s->host_flags;
+    s->host_flags = nullptr;
+    s->stream = s->stream2 = nullptr;
+    s->ev0 = s->ev1 = nullptr;
+    s->shaded.clear(), s->lit.clear();
+    if (t.stream && t.stream2 && t.ev0 && t.ev1 && t.shaded.size() <= 64) {
+        std::lock_guard<std::mutex> lk(g_stream_sets_mutex);
+        std::vector<StreamSet> &idle = g_idle_stream_sets[s->device];
+        if (idle.size() < IDLE_STREAM_SETS) {
+            idle.push_back(std::move(t));
+            return;
+        }
+    }
+    destroy_stream_set(t);
+}
+
 // Makes the wavefront state hold at least min(`wanted`, the capacity bound) entries and `shadow_floor` shadow slots
 // (what one batch of the smallest size needs); grows, never shrinks.  A new state gets `shadow_mult` shadow slots per
 // entry.  When the device cannot give that much, half of it is tried, and so on down to 1 Mi entries.
@@ -2079,9 +2145,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     memcpy(D.bg, d->background_color, sizeof D.bg);
     D.bg_tex = d->background_texture;
     D.is_probe = d->is_probe;
-    if (!(s->stats = (unsigned long long *)device_blocks().alloc(2 * STAT_ROWS * STAT_WORDS * sizeof(unsigned long long))) || hipStreamCreate(&s->stream) != hipSuccess ||
-        hipStreamCreate(&s->stream2) != hipSuccess ||
-        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+    if (!(s->stats = (unsigned long long *)device_blocks().alloc(2 * STAT_ROWS * STAT_WORDS * sizeof(unsigned long long))) || !take_stream_set(s)) {
         g_error = "rt_scene_create: cannot allocate stream/events";
         rt_scene_destroy(s);
         return 10;
@@ -2154,17 +2218,11 @@ void rt_scene_destroy(rt_scene *s) {
     clock.mark("destroy: streams, graph, wavefront parked");
     for (void *p : s->allocations) device_blocks().free(p);
     for (void *p : s->wf_allocations) (void)hipFree(p);
-    if (s->host_flags) (void)hipHostFree(s->host_flags);
     device_blocks().free(s->stats);
     device_blocks().free(s->framebuffer);
     device_blocks().free(s->owned_tiles);
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : s->shaded) (void)hipEventDestroy(e);
-    for (hipEvent_t e : s->lit) (void)hipEventDestroy(e);
-    if (s->stream2) (void)hipStreamDestroy(s->stream2);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    park_stream_set(s);
     clock.mark("destroy: buffers, events, streams released");
     delete s;
 }

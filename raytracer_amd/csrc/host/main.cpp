@@ -128,11 +128,81 @@ struct FileJob {
     std::chrono::high_resolution_clock::time_point start;
 };
 
+// 8-bit frames on their way from the device to a writer thread live in pinned host memory that goes round: the copy from
+// the device runs at the link's rate, and no frame pays for fresh pages (a 1080p frame is 6 MB: 1500 page faults and a
+// staged copy otherwise, half a millisecond of the render thread per file).  Blocks are kept until the process ends.
+class PinnedPool {
+public:
+    uint8_t *take(size_t bytes, size_t &room) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t k = 0; k < idle_.size(); ++k)
+                if (idle_[k].second >= bytes) {
+                    uint8_t *p = idle_[k].first;
+                    room = idle_[k].second;
+                    idle_.erase(idle_.begin() + (long)k);
+                    return p;
+                }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        room = bytes;
+        return (uint8_t *)p;
+    }
+    void give(uint8_t *p, size_t room) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (idle_.size() < 64) {
+            idle_.emplace_back(p, room);
+            return;
+        }
+        (void)hipHostFree(p);
+    }
+
+private:
+    std::mutex m_;
+    std::vector<std::pair<uint8_t *, size_t>> idle_;
+};
+static PinnedPool g_pinned_pixels;
+
+class HostPixels {   // n bytes, pinned when the pool can give them, ordinary memory otherwise
+public:
+    HostPixels() = default;
+    explicit HostPixels(size_t n) {
+        pinned_ = g_pinned_pixels.take(n, room_);
+        if (!pinned_) heap_.resize(n);
+    }
+    HostPixels(HostPixels &&o) noexcept : pinned_(o.pinned_), room_(o.room_), heap_(std::move(o.heap_)) { o.pinned_ = nullptr; }
+    HostPixels &operator=(HostPixels &&o) noexcept {
+        if (this != &o) {
+            release();
+            pinned_ = o.pinned_, room_ = o.room_, heap_ = std::move(o.heap_);
+            o.pinned_ = nullptr;
+        }
+        return *this;
+    }
+    HostPixels(const HostPixels &) = delete;
+    HostPixels &operator=(const HostPixels &) = delete;
+    ~HostPixels() { release(); }
+    uint8_t *data() { return pinned_ ? pinned_ : heap_.data(); }
+
+private:
+    void release() {
+        if (pinned_) g_pinned_pixels.give(pinned_, room_);
+        pinned_ = nullptr;
+    }
+    uint8_t *pinned_ = nullptr;
+    size_t room_ = 0;
+    std::vector<uint8_t> heap_;
+};
+
 struct WriteTask {
     enum Kind { PNG_RGB8, EXR_RGB32F } kind;
     std::string path;
     int width, height;
-    std::vector<uint8_t> rgb8;
+    HostPixels rgb8;
     std::vector<float> rgb32f;
 };
 
@@ -338,6 +408,9 @@ private:
                 if (!t.devices.empty() && hipSetDevice(t.devices[0]) == hipSuccess) t.release_buffers();
             }
         } release{team};
+        // the first HIP call on a device takes 0.15 s (the driver makes the process's context): made now, beside the loaders'
+        // first files, not when the first scene arrives
+        if (!team.devices.empty() && hipSetDevice(team.devices[0]) == hipSuccess) (void)hipFree(nullptr);
         for (;;) {
             size_t i;
             const auto t_wait = std::chrono::high_resolution_clock::now();
@@ -493,7 +566,7 @@ private:
                 frame = crew.frame;
             }
             // 8-bit pixels are made in the team's device buffer and copied out (an EXR frame is on the host: the library stages it)
-            auto to_host = [&](std::vector<uint8_t> &pixels) { return exr || hipMemcpy(pixels.data(), crew.ldr, n_values, hipMemcpyDeviceToHost) == hipSuccess; };
+            auto to_host = [&](HostPixels &pixels) { return exr || hipMemcpy(pixels.data(), crew.ldr, n_values, hipMemcpyDeviceToHost) == hipSuccess; };
             uint8_t *const ldr_out_dev = exr ? nullptr : crew.ldr;
             rt_stats stats;
             if (n_ranks == 1) {
@@ -533,7 +606,7 @@ private:
 
             std::vector<WriteTask> tasks;
             if (!exr && cam.tonemaps.empty()) {
-                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + name, W, H, std::vector<uint8_t>(n_values), {}};
+                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + name, W, H, HostPixels(n_values), {}};
                 if (rt_quantize_ldr(frame, (int64_t)n_values, ldr_out_dev ? ldr_out_dev : t.rgb8.data()) != 0 || !to_host(t.rgb8)) {
                     job_printf(job, "rt_quantize_ldr failed: %s\n", rt_last_error());
                     fail(index, -1);
@@ -544,7 +617,7 @@ private:
                 std::string base = name;
                 size_t dot = base.find_last_of('.');
                 if (dot != std::string::npos) base = base.substr(0, dot);
-                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + base + tm.extension, W, H, std::vector<uint8_t>(n_values), {}};
+                WriteTask t{WriteTask::PNG_RGB8, "outputs/" + base + tm.extension, W, H, HostPixels(n_values), {}};
                 const rt_tonemap_desc td{tm.type, tm.opt1, tm.opt2, tm.saturation, tm.gamma};
                 if (rt_tonemap(frame, W, H, &td, ldr_out_dev ? ldr_out_dev : t.rgb8.data()) != 0 || !to_host(t.rgb8)) {
                     job_printf(job, "rt_tonemap failed: %s\n", rt_last_error());
