@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -435,7 +436,13 @@ bool write_png_rgb8(const std::string &path, int w, int h, const uint8_t *rgb, b
     }
     uLongf clen = compressBound((uLong)raw.size());
     std::vector<uint8_t> comp(clen);
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    // zlib level 6 unless RT_PNG_LEVEL (1 .. 9) says otherwise: the pixels are the same at every level, size and time are not
+    static const int level = [] {
+        const char *e = getenv("RT_PNG_LEVEL");
+        const int v = e ? atoi(e) : 6;
+        return v >= 1 && v <= 9 ? v : 6;
+    }();
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), level) != Z_OK) return false;
     comp.resize(clen);
     std::vector<uint8_t> out = {137, 80, 78, 71, 13, 10, 26, 10};
     std::vector<uint8_t> ihdr;

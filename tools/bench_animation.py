@@ -37,6 +37,8 @@ for k, (label, exe, env) in enumerate(runs):
     t0 = time.perf_counter()
     r = subprocess.run([exe, frames], cwd=cwd, capture_output=True, text=True, env=dict(os.environ, **env))
     dt = time.perf_counter() - t0
-    done = sum(1 for f in os.listdir(os.path.join(cwd, "outputs")) if f.endswith(".png"))
-    print(f"{label}: {n} frames in {dt:.2f} s = {n / dt:.1f} frames/s ({done} PNGs written, exit {r.returncode})")
+    pngs = [os.path.join(cwd, "outputs", f) for f in os.listdir(os.path.join(cwd, "outputs")) if f.endswith(".png")]
+    done = len(pngs)
+    size = sum(os.path.getsize(f) for f in pngs) / max(1, done) / 1e6
+    print(f"{label}: {n} frames in {dt:.2f} s = {n / dt:.1f} frames/s ({done} PNGs written, {size:.2f} MB each, exit {r.returncode})")
 shutil.rmtree(work, ignore_errors=True)
