@@ -24,7 +24,7 @@ runs = [("this repository", EXE, {}),
         ("reference executable", os.path.join(ROOT, "oracle", "_ref", "raytracer"), {})]
 if "--no-reference" in sys.argv:
     runs.pop()
-if "--against-old" in sys.argv:   # A/B on one box: a build of an earlier commit under ab_old/ (tools: see DESIGN), three runs each in turn
+if "--against-old" in sys.argv:   # A/B on one box: a build of an earlier commit (its raytracer and raytracer_amd/*.so copied to ab_old/), three runs each in turn
     old = os.path.join(ROOT, "ab_old", "raytracer")
     runs = [(f"{label} [{which}, run {r}]", exe if which == "new" else old, env) for r in range(3) for label, exe, env in runs[:2] for which in ("old", "new")]
 if "--render-threads" in sys.argv:   # several render threads on the one GPU (RT_GPUS_DEVICES names it more than once)
