@@ -401,13 +401,26 @@ __device__ bool quantise_axis(const float lo_of[4], const float hi_of[4], const 
     }
 }
 
+// Quantises the (up to) four boxes of a record and writes it; false when the grid cannot hold them.
+__device__ bool write_wide_record(const float lo_of[3][4], const float hi_of[3][4], const bool present[4], const unsigned ref[4], unsigned head_bits, float4 *o) {
+    float origin[3], step[3];
+    unsigned qlo[3], qhi[3];
+    for (int a = 0; a < 3; ++a)
+        if (!quantise_axis(lo_of[a], hi_of[a], present, origin[a], step[a], qlo[a], qhi[a])) return false;
+    o[0] = make_float4(origin[0], origin[1], origin[2], __uint_as_float(__float_as_uint(step[0]) | head_bits));
+    o[1] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    o[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qhi[0]), __uint_as_float(qlo[1]), __uint_as_float(qhi[1]));
+    o[3] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[2]), step[1], step[2]);
+    return true;
+}
+
 __global__ void __launch_bounds__(256) ploc_wide_records_kernel(const float *__restrict__ bounds, const unsigned *__restrict__ order, int ni, TreeArrays T,
                                                                  const int *__restrict__ place, const int *__restrict__ first_entry,
                                                                  const int *__restrict__ wide_record_of, float4 *__restrict__ wnodes, int *__restrict__ unsound) {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= ni || wide_record_of[id] < 0) return;
     const int kids[2] = {T.left[id], T.right[id]};
-    int slot[4];                 // node or ~position; slot_used says whether there is one
+    int slot[4];                 // node or ~position; `present` says whether there is one
     bool present[4];
     unsigned head_bits = (unsigned)T.axis_bit[id];
     for (int k = 0; k < 2; ++k) {
@@ -439,18 +452,7 @@ __global__ void __launch_bounds__(256) ploc_wide_records_kernel(const float *__r
         else
             ref[k] = (unsigned)wide_record_of[c];
     }
-    float origin[3], step[3];
-    unsigned qlo[3], qhi[3];
-    for (int a = 0; a < 3; ++a)
-        if (!quantise_axis(lo_of[a], hi_of[a], present, origin[a], step[a], qlo[a], qhi[a])) {
-            *unsound = 1;
-            return;
-        }
-    float4 *o = wnodes + 4 * (size_t)wide_record_of[id];
-    o[0] = make_float4(origin[0], origin[1], origin[2], __uint_as_float(__float_as_uint(step[0]) | head_bits));
-    o[1] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
-    o[2] = make_float4(__uint_as_float(qlo[0]), __uint_as_float(qhi[0]), __uint_as_float(qlo[1]), __uint_as_float(qhi[1]));
-    o[3] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[2]), step[1], step[2]);
+    if (!write_wide_record(lo_of, hi_of, present, ref, head_bits, wnodes + 4 * (size_t)wide_record_of[id])) *unsound = 1;
 }
 
 // Leaf entry and shading record of sorted position j, written to its place: scaled vertex and edges as the reference
@@ -535,6 +537,95 @@ __global__ void __launch_bounds__(256) node_records_kernel(const rt_bvh_node *__
     o[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
     o[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
     o[3] = make_float4(__int_as_float(lr), __int_as_float(rr), __int_as_float(1 << n.axis), 0.f);
+}
+
+// ---- four-box records of a tree that came with the scene ---------------------------------------------------------------
+// The reference's array holds a node, its left subtree, its right subtree (src/bvh.cpp:316-344): the left child of interior
+// node i is i + 1, the right one nodes[i].offset.
+__global__ void __launch_bounds__(256) tree_parents_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, int *__restrict__ parent) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    if (i == 0) parent[0] = -1;
+    if (nodes[i].n_prims != 0) return;
+    parent[i + 1] = i;
+    parent[nodes[i].offset] = i;
+}
+
+// head[i] = 1 when node i heads a record: an interior node an even number of steps below the root.  On its way to the root
+// a head also adds up what a walk keeps waiting on the stack above it -- every record holds its slots but one -- and the
+// largest such sum over all heads is the stack the deepest walk needs (build_wide_nodes of rt_wide.h computes the same
+// number bottom-up).
+__global__ void __launch_bounds__(256) tree_heads_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, const int *__restrict__ parent, int *__restrict__ head,
+                                                          int *__restrict__ stack_need) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    if (nodes[i].n_prims != 0) {
+        head[i] = 0;
+        return;
+    }
+    auto waiting = [&](int a) {   // slots of the record a heads, less the one the walk goes on with
+        const int l = a + 1, r = nodes[a].offset;
+        return 1 + (nodes[l].n_prims == 0 ? 1 : 0) + (nodes[r].n_prims == 0 ? 1 : 0);
+    };
+    int depth = 0, even = waiting(i), odd = 0;   // sums over the ancestors an even / odd number of steps up (this node: zero steps)
+    for (int a = parent[i]; a >= 0; a = parent[a]) {
+        ++depth;
+        if (depth & 1) odd += waiting(a); else even += waiting(a);
+    }
+    const bool is_head = (depth & 1) == 0;
+    head[i] = is_head ? 1 : 0;
+    if (is_head) atomicMax(stack_need, even);
+}
+
+// where[i]: the record of head i -- its number among the heads in array order behind the places of the top, unless it is one
+// of the top heads (listed breadth-first in `top`), whose place is its number there.
+__global__ void __launch_bounds__(256) tree_wide_places_kernel(int n_nodes, const int *__restrict__ head, const int *__restrict__ rank, int top_places, int *__restrict__ where) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    where[i] = head[i] ? top_places + rank[i] : -1;
+}
+__global__ void tree_wide_top_kernel(const int *__restrict__ top, int n_top, int *__restrict__ where) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_top) where[top[k]] = k;
+}
+
+__global__ void __launch_bounds__(256) tree_wide_records_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, const int *__restrict__ where, float4 *__restrict__ wnodes,
+                                                                 int *__restrict__ unsound) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes || where[i] < 0) return;
+    const int kids[2] = {i + 1, nodes[i].offset};
+    int slot[4];
+    bool present[4];
+    unsigned head_bits = 1u << nodes[i].axis;
+    for (int k = 0; k < 2; ++k) {
+        const int c = kids[k];
+        if (nodes[c].n_prims != 0) {
+            slot[2 * k] = c, present[2 * k] = true;
+            slot[2 * k + 1] = 0, present[2 * k + 1] = false;
+        } else {
+            slot[2 * k] = c + 1, slot[2 * k + 1] = nodes[c].offset;
+            present[2 * k] = present[2 * k + 1] = true;
+            head_bits |= 1u << (3 + 3 * k + nodes[c].axis);
+        }
+    }
+    unsigned ref[4];
+    float lo_of[3][4], hi_of[3][4];
+    for (int k = 0; k < 4; ++k) {
+        if (!present[k]) {
+            ref[k] = 0x40000000u;
+            for (int a = 0; a < 3; ++a) lo_of[a][k] = hi_of[a][k] = 0.0f;
+            continue;
+        }
+        const rt_bvh_node c = nodes[slot[k]];
+        for (int a = 0; a < 3; ++a) lo_of[a][k] = c.bmin[a], hi_of[a][k] = c.bmax[a];
+        if (!(c.bmin[0] <= c.bmax[0] && c.bmin[1] <= c.bmax[1] && c.bmin[2] <= c.bmax[2]) || isinf(c.bmin[0]) || isinf(c.bmin[1]) || isinf(c.bmin[2]) || isinf(c.bmax[0]) ||
+            isinf(c.bmax[1]) || isinf(c.bmax[2])) {   // (a box that is not finite: the scene stays on the two-box records)
+            *unsound = 1;
+            return;
+        }
+        ref[k] = c.n_prims != 0 ? (0x80000000u | (unsigned)c.offset) : (unsigned)where[slot[k]];
+    }
+    if (!write_wide_record(lo_of, hi_of, present, ref, head_bits, wnodes + 4 * (size_t)where[i])) *unsound = 1;
 }
 
 }  // namespace
@@ -718,7 +809,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
 }
 
 int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
-                         int n_triangles, const rt_instance *d_instances, float id_scale, DeviceBvh &out, std::string &err) {
+                         int n_triangles, const rt_instance *d_instances, float id_scale, bool keep_nodes, DeviceBvh &out, std::string &err) {
     out = DeviceBvh();
     Scratch mem;
     rt_bvh_node *d_nodes_in = mem.get<rt_bvh_node>((size_t)n_nodes);
@@ -747,9 +838,59 @@ int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *recor
     BVH_HIP_OK(hipDeviceSynchronize());
     out.nodes = d_records, out.prims = d_prims, out.prim_meta = d_meta;
     out.n_interior = n_records;
+    if (keep_nodes) {
+        out.tree_nodes = d_nodes_in;
+        mem.release(d_nodes_in);
+    }
     mem.release(d_records);
     mem.release(d_prims);
     mem.release(d_meta);
+    return 0;
+}
+
+int wide_records_of_host_tree(const rt_bvh_node *d_nodes, int n_nodes, const int *top, int n_top, int stack_entries, DeviceBvh &out, std::string &err) {
+    out.wide_nodes = nullptr, out.n_wide = 0, out.n_wide_top = 0;
+    if (n_nodes < 3 || n_top < 1 || n_top > TOP_RECORDS) return 0;
+    Scratch mem;
+    int *parent = mem.get<int>((size_t)n_nodes), *head = mem.get<int>((size_t)n_nodes + 1), *rank = mem.get<int>((size_t)n_nodes + 1), *where = mem.get<int>((size_t)n_nodes);
+    int *d_top = mem.get<int>((size_t)TOP_RECORDS), *words = mem.get<int>(2);   // {stack a walk needs, 1 when a record could not be made}
+    size_t scan_bytes = 0;
+    BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, rank, n_nodes + 1));
+    void *scan_temp = mem.get<char>(scan_bytes);
+    if (!parent || !head || !rank || !where || !d_top || !words || !scan_temp) {
+        err = "out of device memory for the wide tree";
+        return 10;
+    }
+    const unsigned blocks = (unsigned)((n_nodes + 255) / 256);
+    BVH_HIP_OK(hipMemcpy(d_top, top, (size_t)n_top * sizeof(int), hipMemcpyHostToDevice));
+    BVH_HIP_OK(hipMemsetAsync(words, 0, 2 * sizeof(int), 0));
+    BVH_HIP_OK(hipMemsetAsync(head + n_nodes, 0, sizeof(int), 0));   // the scan's last element: the number of heads
+    hipLaunchKernelGGL(tree_parents_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes, n_nodes, parent);
+    hipLaunchKernelGGL(tree_heads_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes, n_nodes, (const int *)parent, head, words);
+    BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, head, rank, n_nodes + 1));
+    BVH_HIP_OK(hipGetLastError());
+    int n_heads = 0, need = 0;
+    BVH_HIP_OK(hipMemcpy(&n_heads, rank + n_nodes, sizeof n_heads, hipMemcpyDeviceToHost));
+    BVH_HIP_OK(hipMemcpy(&need, words, sizeof need, hipMemcpyDeviceToHost));
+    if (n_heads < 1 || need > stack_entries) return 0;   // (a walk could need more stack than the trace kernel has: two-box records)
+    const size_t n_records = (size_t)TOP_RECORDS + (size_t)n_heads;
+    float4 *d_wnodes = mem.get<float4>(4 * n_records);
+    if (!d_wnodes) {
+        err = "out of device memory for the wide tree";
+        return 10;
+    }
+    BVH_HIP_OK(hipMemsetAsync(d_wnodes, 0, 4 * n_records * sizeof(float4), 0));
+    hipLaunchKernelGGL(tree_wide_places_kernel, dim3(blocks), dim3(256), 0, 0, n_nodes, (const int *)head, (const int *)rank, TOP_RECORDS, where);
+    hipLaunchKernelGGL(tree_wide_top_kernel, dim3(1), dim3(128), 0, 0, (const int *)d_top, n_top, where);
+    hipLaunchKernelGGL(tree_wide_records_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes, n_nodes, (const int *)where, d_wnodes, words + 1);
+    BVH_HIP_OK(hipGetLastError());
+    int unsound = 1;
+    BVH_HIP_OK(hipMemcpy(&unsound, words + 1, sizeof unsound, hipMemcpyDeviceToHost));
+    if (unsound) return 0;
+    out.wide_nodes = d_wnodes;
+    out.n_wide = (int)n_records;
+    out.n_wide_top = n_top;
+    mem.release(d_wnodes);
     return 0;
 }
 

@@ -1413,10 +1413,12 @@ struct rt_scene {
     float *framebuffer = nullptr;
     size_t framebuffer_floats = 0;
     bool counters = false;
-    // The wide tree costs host time to build (about 50 ms per million BVH nodes) and saves device time per ray, so it is
-    // built when the scene has been asked for enough rays to repay it; until then the two-box records serve.
+    // The wide tree takes a few launches over the nodes to build and saves device time per ray, so it is built when the
+    // scene has been asked for enough rays to repay it; until then the two-box records serve.
     // RT_WIDE_NODES=1: at scene creation, =0: never.
-    std::vector<rt_bvh_node> host_nodes;   // kept while the wide tree may still be built
+    rt_bvh_node *tree_nodes = nullptr;     // the scene's node array on the device, kept while the wide tree may still be built
+    int tree_node_count = 0;
+    std::vector<int> wide_top;             // the nodes that head the first wide records, breadth-first (see build_wide_nodes in rt_wide.h)
     unsigned long long paths_seen = 0;
     int device = 0;
     hipStream_t stream = nullptr;    // generate, closest-hit trace, shade, resolve
@@ -1860,39 +1862,36 @@ struct CreateClock {
     }
 };
 
-// Builds and uploads the wide tree from the kept copy of the BVH (which is released either way).  A tree that does not
-// qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
+// Builds the wide tree on the device from the kept copy of the scene's node array (which is released either way).  A tree
+// that does not qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
 static int build_wide_tree(rt_scene *s) {
-    std::vector<rt_bvh_node> nodes;
-    nodes.swap(s->host_nodes);
-    if (nodes.empty()) return 0;
-    std::vector<WideRecord> records;   // 64 bytes each, read as 4 x float4 on the device
-    int root_ref = 0, n_top = 0;
-    if (!build_wide_nodes(nodes.data(), (int)nodes.size(), std::max(TOP_NODES, RT_ANY_TOP_NODES), LDS_STACK + SPILL_STACK, records, root_ref, n_top)) return 0;
-    static_assert(sizeof(WideRecord) == 4 * sizeof(float4), "a wide record is four float4");
-    float4 *dev = nullptr;
+    rt_bvh_node *nodes = s->tree_nodes;
+    s->tree_nodes = nullptr;
+    if (!nodes) return 0;
     HIP_OK(hipSetDevice(s->device));
-    dev = (float4 *)device_blocks().alloc(records.size() * sizeof(WideRecord));
-    if (!dev) {
-        g_error = "out of device memory for the wide tree";
-        return 10;
-    }
-    s->allocations.push_back(dev);
-    HIP_OK(hipMemcpy(dev, records.data(), records.size() * sizeof(WideRecord), hipMemcpyHostToDevice));
-    s->dev.wroot_ref = root_ref;
-    s->dev.n_wtop = n_top;
-    s->dev.wnodes = dev;
+    HIP_OK(hipStreamSynchronize(s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream2));
+    DeviceBvh built;
+    const int rc = wide_records_of_host_tree(nodes, s->tree_node_count, s->wide_top.data(), (int)s->wide_top.size(), LDS_STACK + SPILL_STACK, built, g_error);
+    device_blocks().free(nodes);
+    s->wide_top.clear();
+    if (rc) return rc;
+    if (!built.wide_nodes) return 0;
+    s->allocations.push_back(built.wide_nodes);
+    s->dev.wroot_ref = 0;
+    s->dev.n_wtop = built.n_wide_top;
+    s->dev.wnodes = built.wide_nodes;
     return 0;
 }
 
 // Called by every render with the number of camera paths it is about to trace: the wide tree is built once the scene
-// has been asked for 256 paths per BVH node, about where its host time is repaid (measured: the 1M-triangle scene builds
-// in 50 ms and saves 0.28 ms per million paths, the 70 K-triangle scene at 1 spp builds in 6 ms and saves 0.06 ms per
-// million).  That is at once for the 1M-triangle scene's 4K frames, and with the sixteenth 1080p frame of the 70 K one.
+// has been asked for 32 paths per BVH node, about where the build is repaid (the walk of the 1M-triangle scene saves 0.28 ms
+// per million paths, that of the 70 K-triangle scene at 1 spp 0.06 ms per million; the build takes a few launches over the
+// nodes).  That is at once for the 1M-triangle scene's frames, and with the third 1080p frame of the 70 K one.
 static int account_paths(rt_scene *s, unsigned long long paths) {
-    if (s->host_nodes.empty()) return 0;
+    if (!s->tree_nodes) return 0;
     s->paths_seen += paths;
-    if (s->paths_seen < 256ull * s->host_nodes.size()) return 0;
+    if (s->paths_seen < 32ull * (unsigned long long)s->tree_node_count) return 0;
     return build_wide_tree(s);
 }
 
@@ -2082,10 +2081,28 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         }
         root_ref = built.root_ref;
         s->dev.n_top = built.n_top;   // the builder puts the top levels first, as the host's layout does
-    } else if (int rc = records_of_host_tree(d->bvh_nodes, d->n_bvh_nodes, interior_index.data(), n_interior, d->bvh_prims, d->n_bvh_prims, D.triangles, d->n_triangles,
-                                             D.instances, id_scale, built, g_error)) {
-        rt_scene_destroy(s);
-        return rc;
+    } else {
+        const char *wide_env = getenv("RT_WIDE_NODES");
+        const bool keep_nodes = !(wide_env && atoi(wide_env) == 0) && d->n_bvh_nodes >= 3 && d->bvh_nodes[0].n_prims == 0;
+        if (int rc = records_of_host_tree(d->bvh_nodes, d->n_bvh_nodes, interior_index.data(), n_interior, d->bvh_prims, d->n_bvh_prims, D.triangles, d->n_triangles,
+                                          D.instances, id_scale, keep_nodes, built, g_error)) {
+            rt_scene_destroy(s);
+            return rc;
+        }
+        if (built.tree_nodes) {   // the heads of the first wide records, breadth-first, while the nodes are at hand on the host
+            s->tree_nodes = built.tree_nodes;
+            s->tree_node_count = d->n_bvh_nodes;
+            std::vector<int> walk{0};
+            const int most = std::max(TOP_NODES, RT_ANY_TOP_NODES);
+            for (size_t at = 0; at < walk.size() && (int)s->wide_top.size() < most; ++at) {
+                const int i = walk[at];
+                s->wide_top.push_back(i);
+                int slot[4], ax[3];
+                wide_slots(d->bvh_nodes, i, slot, ax);
+                for (int k = 0; k < 4; ++k)
+                    if (slot[k] >= 0 && d->bvh_nodes[slot[k]].n_prims == 0) walk.push_back(slot[k]);
+            }
+        }
     }
     D.nodes = built.nodes, D.prims = built.prims, D.prim_meta = built.prim_meta;
     for (void *p : {(void *)built.nodes, (void *)built.prims, (void *)built.prim_meta, (void *)built.wide_nodes})
@@ -2127,7 +2144,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     {
         const char *e = getenv("RT_WIDE_NODES");
         const int mode = e ? atoi(e) : -1;
-        if (mode != 0 && d->n_bvh_nodes >= 3 && d->bvh_nodes[0].n_prims == 0) s->host_nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
         if (mode > 0 && build_wide_tree(s) != 0) {
             rt_scene_destroy(s);
             return 10;
@@ -2218,6 +2234,7 @@ void rt_scene_destroy(rt_scene *s) {
     clock.mark("destroy: streams, graph, wavefront parked");
     for (void *p : s->allocations) device_blocks().free(p);
     for (void *p : s->wf_allocations) (void)hipFree(p);
+    device_blocks().free(s->tree_nodes);
     device_blocks().free(s->stats);
     device_blocks().free(s->framebuffer);
     device_blocks().free(s->owned_tiles);

@@ -17,6 +17,7 @@ struct DeviceBvh {
     float4 *wide_nodes = nullptr; // four-box records (DevScene::wnodes), record 0 heads the root; nullptr when the tree has none
     int n_wide = 0;               // records allocated (places the tree does not use are zero)
     int n_wide_top = 0;           // the first n_wide_top of them are the top of the tree, breadth-first (DevScene::n_wtop)
+    rt_bvh_node *tree_nodes = nullptr;   // records_of_host_tree with keep_nodes: the scene's node array on the device
     int root_ref = 0;
     int depth = 0;                // interior nodes on the longest root-to-leaf path
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
@@ -32,7 +33,15 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
 // The records of a tree that came with the scene, made on the device from the reference's node array (src/bvh.h:9-28; nodes,
 // record_of and prims in host memory): `record_of[i]` is where interior node i's two-box record goes (n_records places in
 // all), leaf entries keep the order of `prims`.  Fills out.nodes, out.prims, out.prim_meta (owned by the caller, as above).
+// `keep_nodes`: the uploaded node array stays on the device (out.tree_nodes, owned by the caller) for wide_records_of_host_tree.
 int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
-                         int n_triangles, const rt_instance *d_instances, float id_scale, DeviceBvh &out, std::string &err);
+                         int n_triangles, const rt_instance *d_instances, float id_scale, bool keep_nodes, DeviceBvh &out, std::string &err);
+
+// The four-box records (DevScene::wnodes) of a tree that came with the scene, from its node array on the device: the records
+// build_wide_nodes of rt_wide.h makes on the host, in another order below the top.  `top`: the first heads breadth-first (host
+// memory, at most 127; record k heads node top[k], top[0] = 0 the root); `stack_entries`: the stack a walk has.  Fills
+// out.wide_nodes / n_wide / n_wide_top; leaves them empty (and returns 0) when the tree does not qualify: a box that is not
+// finite, or a walk that could need more stack.
+int wide_records_of_host_tree(const rt_bvh_node *d_nodes, int n_nodes, const int *top, int n_top, int stack_entries, DeviceBvh &out, std::string &err);
 
 }  // namespace rt

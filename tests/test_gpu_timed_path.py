@@ -32,6 +32,7 @@ def test_timed_path_matches_oracle(name, scene_dir, repo_root, monkeypatch):
     cam = sc.camera(0)
     orc = Oracle(sc)
     ren = R.Renderer(sc)                       # counters stay off
+    assert ren.wide_records() == (sc.desc.n_bvh_nodes >= 3), "the scene did not get its four-box records"
     s0, i0, t0, _ = orc.trace_primary(cam)
     s1, i1, t1, st = ren.trace_primary(cam)
     assert st.nodes_visited == 0, "the counted walk ran"
@@ -51,7 +52,9 @@ def test_full_size_primary_hits_match_oracle(scene_dir, monkeypatch):
     monkeypatch.setenv("RT_WIDE_NODES", "1")
     sc = R.Scene(scenegen.write_path_traced_scene(scene_dir + "/pt1m_4k", width=3840, height=2160, spp=16))
     cam = sc.camera(0)
-    s1, i1, t1, st = R.Renderer(sc).trace_primary(cam)
+    ren = R.Renderer(sc)
+    assert ren.wide_records()
+    s1, i1, t1, st = ren.trace_primary(cam)
     s0, i0, t0, _ = Oracle(sc).trace_primary(cam)
     assert st.nodes_visited == 0 and len(s1) == 3840 * 2160 and (s1 >= 0).sum() > 4_000_000
     assert np.array_equal(s0, s1) and np.array_equal(i0, i1)
