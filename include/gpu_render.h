@@ -308,6 +308,11 @@ int32_t rt_scene_plain_shading(const rt_scene *scene);
  * records (src/bvh.cpp:383-480) -- made on the host once the scene has traced enough rays to repay them (RT_WIDE_NODES=1: at
  * rt_scene_create), or with the tree when that is built on the device; RT_WIDE_NODES=0: never. */
 int32_t rt_scene_wide_records(const rt_scene *scene);
+/* Test hook: runs the builder of the four-box records on a bare node array (n_nodes >= 3, nodes[0] interior; the layout of
+ * bvh::nodes, src/bvh.h:9-22) with a walk's stack of `stack_entries`.  Returns the number of records the tree gets, -1 when
+ * the builder declines it (a walk could need more stack, or a box is not finite: such a scene renders from the node-by-node
+ * records), -2 on a malformed array or an error. */
+int64_t rt_selftest_wide_records(const rt_bvh_node *nodes, int32_t n_nodes, int32_t stack_entries);
 
 /* ---- one frame on several GPUs (src/main.cpp:437-555 with a GPU in the place of a thread) -----------------------------
  * Every rank holds a replica of the scene (rt_scene_create on its device) and a communicator.  rt_render_gather renders

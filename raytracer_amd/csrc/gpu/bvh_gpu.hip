@@ -793,6 +793,7 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
                 if (!words[1]) {   // (a record that could not be made leaves the scene on the two-box records)
                     out.wide_nodes = d_wnodes;
                     out.n_wide = TOP_RECORDS + root_wide.x;
+                    out.n_wide_heads = root_wide.x;
                     out.n_wide_top = words[0];
                     mem.release(d_wnodes);
                 }
@@ -889,6 +890,7 @@ int wide_records_of_host_tree(const rt_bvh_node *d_nodes, int n_nodes, const int
     if (unsound) return 0;
     out.wide_nodes = d_wnodes;
     out.n_wide = (int)n_records;
+    out.n_wide_heads = n_heads;
     out.n_wide_top = n_top;
     mem.release(d_wnodes);
     return 0;

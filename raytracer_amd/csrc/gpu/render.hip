@@ -1862,6 +1862,22 @@ struct CreateClock {
     }
 };
 
+// The nodes that head the first wide records: the root and the heads a breadth-first walk meets next, as many as the trace
+// kernels keep in LDS (the order build_wide_nodes of rt_wide.h gives the top of the tree).  The root must be interior.
+static std::vector<int> wide_top_of(const rt_bvh_node *nodes) {
+    std::vector<int> top, walk{0};
+    const int most = std::max(TOP_NODES, RT_ANY_TOP_NODES);
+    for (size_t at = 0; at < walk.size() && (int)top.size() < most; ++at) {
+        const int i = walk[at];
+        top.push_back(i);
+        int slot[4], ax[3];
+        wide_slots(nodes, i, slot, ax);
+        for (int k = 0; k < 4; ++k)
+            if (slot[k] >= 0 && nodes[slot[k]].n_prims == 0) walk.push_back(slot[k]);
+    }
+    return top;
+}
+
 // Builds the wide tree on the device from the kept copy of the scene's node array (which is released either way).  A tree
 // that does not qualify leaves the scene on the two-box records; only a failed allocation or copy is an error.
 static int build_wide_tree(rt_scene *s) {
@@ -2092,16 +2108,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         if (built.tree_nodes) {   // the heads of the first wide records, breadth-first, while the nodes are at hand on the host
             s->tree_nodes = built.tree_nodes;
             s->tree_node_count = d->n_bvh_nodes;
-            std::vector<int> walk{0};
-            const int most = std::max(TOP_NODES, RT_ANY_TOP_NODES);
-            for (size_t at = 0; at < walk.size() && (int)s->wide_top.size() < most; ++at) {
-                const int i = walk[at];
-                s->wide_top.push_back(i);
-                int slot[4], ax[3];
-                wide_slots(d->bvh_nodes, i, slot, ax);
-                for (int k = 0; k < 4; ++k)
-                    if (slot[k] >= 0 && d->bvh_nodes[slot[k]].n_prims == 0) walk.push_back(slot[k]);
-            }
+            s->wide_top = wide_top_of(d->bvh_nodes);
         }
     }
     D.nodes = built.nodes, D.prims = built.prims, D.prim_meta = built.prim_meta;
@@ -2735,6 +2742,22 @@ uint64_t rt_queue_fill_bound(uint32_t groups_per_sample, uint32_t samples) { ret
 int32_t rt_scene_shadow_order_free(const rt_scene *s) { return s && s->shadow_order_free ? 1 : 0; }
 int32_t rt_scene_plain_shading(const rt_scene *s) { return s && s->plain_shading ? 1 : 0; }
 int32_t rt_scene_wide_records(const rt_scene *s) { return s && s->dev.wnodes ? 1 : 0; }
+
+int64_t rt_selftest_wide_records(const rt_bvh_node *nodes, int32_t n_nodes, int32_t stack_entries) {
+    if (!nodes || n_nodes < 3 || nodes[0].n_prims != 0) return -1;
+    for (int i = 0; i < n_nodes; ++i)   // (the kernels follow these indices)
+        if (nodes[i].n_prims == 0 && !(nodes[i].offset > i && nodes[i].offset < n_nodes && i + 1 < n_nodes && nodes[i].axis >= 0 && nodes[i].axis < 3)) return -2;
+    rt_bvh_node *dev = nullptr;
+    if (upload<rt_bvh_node>(nodes, (size_t)n_nodes, &dev)) return -2;
+    const std::vector<int> top = wide_top_of(nodes);
+    DeviceBvh built;
+    const int rc = wide_records_of_host_tree(dev, n_nodes, top.data(), (int)top.size(), stack_entries, built, g_error);
+    device_blocks().free(dev);
+    if (rc) return -2;
+    if (!built.wide_nodes) return -1;
+    device_blocks().free(built.wide_nodes);
+    return built.n_wide_heads;
+}
 int32_t rt_shadow_order_free(const rt_scene_desc *d) { return d && d->abi_version == RT_ABI_VERSION && shadow_answers_order_free(d) ? 1 : 0; }
 
 // Host-only: which rank renders which 32x32 tile (shard_owner); a rank's list of tiles is the tiles it owns in row-major

@@ -16,6 +16,7 @@ struct DeviceBvh {
     int n_top = 0;                // the first n_top records are the top levels of the tree, level by level (DevScene::n_top)
     float4 *wide_nodes = nullptr; // four-box records (DevScene::wnodes), record 0 heads the root; nullptr when the tree has none
     int n_wide = 0;               // records allocated (places the tree does not use are zero)
+    int n_wide_heads = 0;         // records the tree uses
     int n_wide_top = 0;           // the first n_wide_top of them are the top of the tree, breadth-first (DevScene::n_wtop)
     rt_bvh_node *tree_nodes = nullptr;   // records_of_host_tree with keep_nodes: the scene's node array on the device
     int root_ref = 0;

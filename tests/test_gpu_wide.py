@@ -40,21 +40,45 @@ def test_wide_walk_equals_two_box_walk(name, scene_dir, monkeypatch):
 
 
 def test_the_switch_to_the_wide_tree_is_invisible(scene_dir, monkeypatch):
-    """By default a scene gets its wide tree once it has been asked for 256 camera paths per BVH node (building it costs
-    host time that few rays do not repay): the 70 K-triangle scene changes walks with its sixteenth 1080p frame.  The
-    frames before and after are the same."""
+    """By default a scene gets its wide tree once it has been asked for 32 camera paths per BVH node (the build is a few
+    launches over the nodes, which a single small frame does not repay): the 70 K-triangle scene changes walks with its second
+    1080p frame.  The frames before and after are the same."""
     monkeypatch.delenv("RT_WIDE_NODES", raising=False)
     sc = R.Scene(path_of("mesh70k", scene_dir))
-    assert 15 * 1920 * 1080 < 256 * sc.desc.n_bvh_nodes < 16 * 1920 * 1080      # the sixteenth frame is the first on the wide tree
+    assert 1 * 1920 * 1080 < 32 * sc.desc.n_bvh_nodes < 2 * 1920 * 1080         # the second frame is the first on the wide tree
     cam = sc.camera(0)
     ren = R.Renderer(sc)
-    frames = [ren.render(cam)[0] for _ in range(18)]
+    assert not ren.wide_records()
+    frames = [ren.render(cam)[0]]
+    assert not ren.wide_records()
+    frames += [ren.render(cam)[0] for _ in range(3)]
+    assert ren.wide_records()
     for f in frames[1:]:
         assert np.abs(f - frames[0]).max() <= 1e-5 * max(1.0, float(frames[0].max()))
     ids = [ren.trace_primary(cam) for _ in range(2)]
     ren.set_counters(True)
     shape_2, id_2, t_2, _ = ren.trace_primary(cam)
     assert np.array_equal(ids[1][0], shape_2) and np.array_equal(ids[1][2].view(np.uint32), t_2.view(np.uint32))
+
+
+def test_device_builder_declines_what_the_walk_cannot_hold():
+    """The builder of the four-box records on the device against the same hand-made trees as the host's builder
+    (tests/test_wide_tree.py): a chain of 40 links gets 20 records; one of 400 would leave 200 entries waiting on a stack of
+    64 and is declined, as is a tree with a box that is not finite (such scenes render from the two-box records)."""
+    import ctypes as C
+    from test_wide_tree import chain_tree
+    g = R.gpu_lib()
+    g.rt_selftest_wide_records.restype = C.c_int64
+    g.rt_selftest_wide_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    nodes, n = chain_tree(40)
+    assert g.rt_selftest_wide_records(nodes, n, 64) == 20
+    nodes, n = chain_tree(400)
+    assert g.rt_selftest_wide_records(nodes, n, 64) == -1
+    assert g.rt_selftest_wide_records(nodes, n, 1000) == 200
+    nodes, n = chain_tree(40, bad_box=True)
+    assert g.rt_selftest_wide_records(nodes, n, 64) == -1
+    nodes, n = chain_tree(41)                                   # an odd chain: the last record holds two leaves
+    assert g.rt_selftest_wide_records(nodes, n, 64) == 21
 
 
 @pytest.mark.parametrize("name", ["materials", "transforms", "mesh70k"])
