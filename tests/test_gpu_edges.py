@@ -284,3 +284,40 @@ def test_repeated_frame_is_replayed_from_a_graph_with_the_same_result(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RT_FRAME_GRAPH="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(np.load(tmp_path / "plain.npy"), first)
+
+
+def test_a_sequence_of_scenes_holds_on_to_nothing(scene_dir, repo_root, monkeypatch):
+    """One scene per file is how a directory of frames runs: create, render, destroy, a few hundred times.  The buffers of a
+    destroyed scene go to a bounded cache (blocks, streams, a parked wavefront state) that the next scene draws on, so the
+    free device memory settles after the first few scenes whatever their order, and every frame is the first one's."""
+    from test_oracle_vs_reference import scene_path
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")   # (the runtime the library runs on is loaded already)
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+    scenes = [R.Scene(scene_path(name, scene_dir, repo_root)) for name in ("simple", "mesh70k", "materials")]
+    monkeypatch.setenv("RT_GPU_BVH", "1")             # (the same scenes without a tree: theirs is built on the device, from the same caches)
+    scenes += [R.Scene(scene_path(name, scene_dir, repo_root)) for name in ("simple", "mesh70k")]
+    monkeypatch.delenv("RT_GPU_BVH")
+    first = {}
+    settled = None
+    for turn in range(90):
+        for mode in ("0", "1"):                       # without and with the four-box records
+            sc = scenes[turn % 3] if turn % 2 == 0 or turn % 3 == 2 else scenes[3 + turn % 3]
+            monkeypatch.setenv("RT_WIDE_NODES", mode)
+            ren = R.Renderer(sc)
+            img, _ = ren.render(sc.camera(0, resx=64, resy=48))
+            ren.close()
+            key = (turn % 3, mode, sc.desc.n_bvh_nodes == 0)
+            if key in first:   # (a scene whose paths split adds a sample's parts in arrival order: equal to the order of float additions)
+                if turn % 3 == 2:
+                    assert (np.abs(img - first[key]) / np.maximum(np.abs(first[key]), 1 / 255)).max() <= 1e-5, key
+                else:
+                    assert np.array_equal(img, first[key]), key
+            else:
+                first[key] = img.copy()
+        if turn == 20:
+            settled = free_bytes()
+    assert settled - free_bytes() < (64 << 20), "device memory keeps going with every scene"
