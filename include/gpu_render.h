@@ -305,7 +305,7 @@ int32_t rt_shadow_order_free(const rt_scene_desc *desc);
  * no texture lookups, no mirror, conductor or dielectric branch.  RT_PLAIN_SHADING=0 at rt_scene_create: never. */
 int32_t rt_scene_plain_shading(const rt_scene *scene);
 /* Test hook: 1 when the scene holds the four-box records that uncounted frames walk instead of bvh::intersect's node-by-node
- * records (src/bvh.cpp:383-480) -- made on the host once the scene has traced enough rays to repay them (RT_WIDE_NODES=1: at
+ * records (src/bvh.cpp:383-480) -- made on the device once the scene has traced enough rays to repay them (RT_WIDE_NODES=1: at
  * rt_scene_create), or with the tree when that is built on the device; RT_WIDE_NODES=0: never. */
 int32_t rt_scene_wide_records(const rt_scene *scene);
 /* Test hook: runs the builder of the four-box records on a bare node array (n_nodes >= 3, nodes[0] interior; the layout of
