@@ -1,7 +1,8 @@
 // Device memory for the buffers a scene lives in and the scratch of its creation: hipMalloc / hipFree behind a small
 // per-device cache of freed blocks.  A directory of frames creates and destroys one scene per file -- some forty buffers of
 // the same sizes every few milliseconds -- and the driver's allocation calls were a third of that; a block that comes back
-// is handed to the next request of (nearly) its size instead.  The cache is bounded (blocks, bytes, block size), holds only
+// is handed to the next request of (nearly) its size instead.  The cache is bounded (blocks, bytes, block size; the blocks that
+// have waited longest go first), holds only
 // blocks whose work has finished (callers synchronise before they free, as hipFree would have), and is per device: a block
 // goes back to the cache of the device it was allocated on.
 #pragma once
@@ -11,6 +12,8 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace rt {
 
@@ -30,7 +33,7 @@ public:
             PerDevice &d = devices_[dev];
             auto it = d.idle.lower_bound(want);
             if (it != d.idle.end() && it->first <= want + want / 8 + 4096) {
-                void *p = it->second;
+                void *p = it->second.first;
                 d.idle_bytes -= it->first;
                 d.live[p] = it->first;
                 d.idle.erase(it);
@@ -51,43 +54,53 @@ public:
         return p;
     }
 
-    // Takes back a block from alloc(); all work that uses it must have finished.
+    // Takes back a block from alloc(); all work that uses it must have finished.  When the cache is full the blocks that
+    // have waited longest make room: what a running sequence of scenes frees is what its next scene asks for.
     void free(void *p) {
         if (!p) return;
-        std::unique_lock<std::mutex> lk(m_);
-        for (auto &entry : devices_) {
-            PerDevice &d = entry.second;
-            auto it = d.live.find(p);
-            if (it == d.live.end()) continue;
-            const size_t size = it->second;
-            d.live.erase(it);
-            if (size <= MAX_BLOCK && d.idle.size() < MAX_BLOCKS && d.idle_bytes + size <= MAX_BYTES) {
-                d.idle.emplace(size, p);
+        std::vector<void *> evicted;
+        bool cached = false;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (auto &entry : devices_) {
+                PerDevice &d = entry.second;
+                auto it = d.live.find(p);
+                if (it == d.live.end()) continue;
+                const size_t size = it->second;
+                d.live.erase(it);
+                if (size > MAX_BLOCK) break;
+                while (!d.idle.empty() && (d.idle.size() >= MAX_BLOCKS || d.idle_bytes + size > MAX_BYTES)) {
+                    auto oldest = d.idle.begin();
+                    for (auto k = d.idle.begin(); k != d.idle.end(); ++k)
+                        if (k->second.second < oldest->second.second) oldest = k;
+                    d.idle_bytes -= oldest->first;
+                    evicted.push_back(oldest->second.first);
+                    d.idle.erase(oldest);
+                }
+                d.idle.emplace(size, std::make_pair(p, ++d.stamp));
                 d.idle_bytes += size;
-                return;
+                cached = true;
+                break;
             }
-            lk.unlock();
-            (void)hipFree(p);
-            return;
         }
-        lk.unlock();
-        (void)hipFree(p);   // (not one of ours)
+        for (void *q : evicted) (void)hipFree(q);
+        if (!cached) (void)hipFree(p);   // (too large to keep, or not one of ours)
     }
 
     // Releases idle blocks of `device` until they hold at most `keep_bytes`.
     void trim(int device, size_t keep_bytes) {
-        std::multimap<size_t, void *> out;
+        std::vector<void *> out;
         {
             std::lock_guard<std::mutex> lk(m_);
             PerDevice &d = devices_[device];
             while (!d.idle.empty() && d.idle_bytes > keep_bytes) {
                 auto it = std::prev(d.idle.end());
                 d.idle_bytes -= it->first;
-                out.insert(*it);
+                out.push_back(it->second.first);
                 d.idle.erase(it);
             }
         }
-        for (auto &b : out) (void)hipFree(b.second);
+        for (void *b : out) (void)hipFree(b);
     }
 
     size_t idle_bytes(int device) {
@@ -97,7 +110,8 @@ public:
 
 private:
     struct PerDevice {
-        std::multimap<size_t, void *> idle;             // size -> block
+        std::multimap<size_t, std::pair<void *, unsigned long long>> idle;   // size -> (block, when it came back)
+        unsigned long long stamp = 0;
         std::unordered_map<void *, size_t> live;        // blocks handed out
         size_t idle_bytes = 0;
     };
