@@ -129,8 +129,11 @@ __global__ void __launch_bounds__(256) ploc_leaves_kernel(const float *__restric
 // 2 m + 1) first, then to the lower (smaller index, larger index): a total order on pairs, so the best pair of a round
 // always choose each other and every round merges at least once -- and a pile of identical boxes pairs off in every round
 // (a balanced tree) instead of growing a chain from one end.
-__global__ void __launch_bounds__(256) ploc_nearest_kernel(const float *__restrict__ box, int nc, int radius, int *__restrict__ nearest) {
+// (The clusters' count of a round, state[0], and the nodes made so far, state[1], live on the device: the host reads them
+// every few rounds only, and launches the rounds in between for the count it last saw -- lanes beyond the true count leave.)
+__global__ void __launch_bounds__(256) ploc_nearest_kernel(const float *__restrict__ box, const int *__restrict__ state, int radius, int *__restrict__ nearest) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nc = state[0];
     if (i >= nc) return;
     float mine[6];
     for (int a = 0; a < 6; ++a) mine[a] = box[6 * (size_t)i + a];
@@ -152,9 +155,14 @@ __global__ void __launch_bounds__(256) ploc_nearest_kernel(const float *__restri
 
 // flags[i]: low word 1 when cluster i survives the round (alone, or as the lower partner of a merge), high word 1 when it
 // is the lower partner of a merge; an exclusive scan of the flags gives the survivor's new place and the new node's number
-__global__ void __launch_bounds__(256) ploc_flag_kernel(const int *__restrict__ nearest, int nc, unsigned long long *__restrict__ flags) {
+__global__ void __launch_bounds__(256) ploc_flag_kernel(const int *__restrict__ nearest, const int *__restrict__ state, int bound, unsigned long long *__restrict__ flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nc) return;
+    if (i > bound) return;
+    const int nc = state[0];
+    if (i >= nc) {   // (the scan runs over bound + 1 flags: its last element holds the totals)
+        flags[i] = 0ull;
+        return;
+    }
     const int j = nearest[i];
     const bool mutual = j >= 0 && nearest[j] == i;
     flags[i] = (mutual && i > j ? 0ull : 1ull) | (mutual && i < j ? 1ull << 32 : 0ull);
@@ -172,10 +180,11 @@ struct TreeArrays {   // per interior node id (in the order the nodes are made: 
 };
 
 __global__ void __launch_bounds__(256) ploc_merge_kernel(const int *__restrict__ nearest, const unsigned long long *__restrict__ flags,
-                                                          const unsigned long long *__restrict__ scanned, int nc, int first_node, const int *__restrict__ ref_in,
+                                                          const unsigned long long *__restrict__ scanned, const int *__restrict__ state, const int *__restrict__ ref_in,
                                                           const float *__restrict__ box_in, const int4 *__restrict__ info_in, int *__restrict__ ref_out,
                                                           float *__restrict__ box_out, int4 *__restrict__ info_out, TreeArrays T) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nc = state[0], first_node = state[1];
     if (i >= nc) return;
     const unsigned long long f = flags[i];
     if (!(f & 1ull)) return;   // merged into its partner
@@ -243,6 +252,14 @@ __global__ void __launch_bounds__(256) ploc_merge_kernel(const int *__restrict__
     }
     ref_out[place] = id;
     info_out[place] = mine;
+}
+
+// After a round: the survivors are the next round's clusters, the merges the nodes made.
+__global__ void ploc_advance_kernel(const unsigned long long *__restrict__ scanned, int bound, int *__restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long totals = scanned[bound];
+    state[0] = (int)(totals & 0xffffffffull);
+    state[1] += (int)(totals >> 32);
 }
 
 // Where every primitive's entry goes: the tree's leaves from left to right, a leaf's primitives next to each other.  One
@@ -722,26 +739,35 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
         const int radius = getenv("RT_GPU_BVH_RADIUS") ? std::max(1, std::min(256, atoi(getenv("RT_GPU_BVH_RADIUS")))) : 8;   // (1M-triangle scene, node visits per ray against the host tree: radius 2 +9 %, 4 +6 %, 8 +3 %, 16 +6 %, 48 +8 %)
         clock.mark("buffers of the clustering");
         hipLaunchKernelGGL(ploc_leaves_kernel, dim3(blocks_n), dim3(256), 0, 0, d_bounds, order, n, ref[0], cbox[0], info[0]);
-        int nc = n, made = 0, cur = 0;
+        int nc = n, cur = 0;
+        int *state = mem.get<int>(2);
+        if (!state) {
+            err = "rt_scene_create: out of device memory for the tree build";
+            return 10;
+        }
+        const int first_state[2] = {n, 0};
+        BVH_HIP_OK(hipMemcpy(state, first_state, sizeof first_state, hipMemcpyHostToDevice));
+        constexpr int ROUNDS_PER_LOOK = 4;   // (a round merges a third of the clusters or more: four rounds leave a fifth)
         while (nc > 1) {
-            const unsigned blocks_c = (unsigned)((nc + 255) / 256);
-            hipLaunchKernelGGL(ploc_nearest_kernel, dim3(blocks_c), dim3(256), 0, 0, cbox[cur], nc, radius, nearest);
-            hipLaunchKernelGGL(ploc_flag_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, nc, flags);
-            BVH_HIP_OK(hipMemsetAsync(flags + nc, 0, sizeof(unsigned long long), 0));   // the scan's last element: the totals
-            BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, flags, scanned, nc + 1));
-            hipLaunchKernelGGL(ploc_merge_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, flags, scanned, nc, made, ref[cur], cbox[cur], info[cur], ref[cur ^ 1],
-                               cbox[cur ^ 1], info[cur ^ 1], T);
+            const int bound = nc;
+            const unsigned blocks_c = (unsigned)((bound + 1 + 255) / 256);
+            for (int round = 0; round < ROUNDS_PER_LOOK; ++round) {
+                hipLaunchKernelGGL(ploc_nearest_kernel, dim3(blocks_c), dim3(256), 0, 0, cbox[cur], (const int *)state, radius, nearest);
+                hipLaunchKernelGGL(ploc_flag_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, (const int *)state, bound, flags);
+                BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, flags, scanned, bound + 1));
+                hipLaunchKernelGGL(ploc_merge_kernel, dim3(blocks_c), dim3(256), 0, 0, nearest, flags, scanned, (const int *)state, ref[cur], cbox[cur], info[cur], ref[cur ^ 1],
+                                   cbox[cur ^ 1], info[cur ^ 1], T);
+                hipLaunchKernelGGL(ploc_advance_kernel, dim3(1), dim3(64), 0, 0, scanned, bound, state);
+                cur ^= 1;
+            }
             BVH_HIP_OK(hipGetLastError());
-            unsigned long long totals = 0;
-            BVH_HIP_OK(hipMemcpy(&totals, scanned + nc, sizeof totals, hipMemcpyDeviceToHost));
-            const int survivors = (int)(totals & 0xffffffffull), merges = (int)(totals >> 32);
-            if (merges < 1 || survivors != nc - merges) {   // (the best pair of a round always choose each other)
+            int now[2] = {0, 0};
+            BVH_HIP_OK(hipMemcpy(now, state, sizeof now, hipMemcpyDeviceToHost));
+            if (now[0] < 1 || now[0] >= nc || now[1] != n - now[0]) {   // (the best pair of a round always choose each other)
                 err = "rt_scene_create: the clustering of the tree build made no progress";
                 return 10;
             }
-            made += merges;
-            nc = survivors;
-            cur ^= 1;
+            nc = now[0];
         }
         clock.mark("clustered");
         int4 root_info;
