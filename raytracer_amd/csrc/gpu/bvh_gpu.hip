@@ -559,6 +559,10 @@ __global__ void __launch_bounds__(256) node_records_kernel(const rt_bvh_node *__
 // ---- four-box records of a tree that came with the scene ---------------------------------------------------------------
 // The reference's array holds a node, its left subtree, its right subtree (src/bvh.cpp:316-344): the left child of interior
 // node i is i + 1, the right one nodes[i].offset.
+__global__ void __launch_bounds__(256) tree_interior_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, int *__restrict__ interior) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_nodes) interior[i] = nodes[i].n_prims == 0 ? 1 : 0;
+}
 __global__ void __launch_bounds__(256) tree_parents_kernel(const rt_bvh_node *__restrict__ nodes, int n_nodes, int *__restrict__ parent) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_nodes) return;
@@ -594,14 +598,15 @@ __global__ void __launch_bounds__(256) tree_heads_kernel(const rt_bvh_node *__re
     if (is_head) atomicMax(stack_need, even);
 }
 
-// where[i]: the record of head i -- its number among the heads in array order behind the places of the top, unless it is one
-// of the top heads (listed breadth-first in `top`), whose place is its number there.
-__global__ void __launch_bounds__(256) tree_wide_places_kernel(int n_nodes, const int *__restrict__ head, const int *__restrict__ rank, int top_places, int *__restrict__ where) {
+// where[i]: the record of node i when head[i] is set (a head of the four-box records, or any interior node for the two-box
+// records) -- its number among such nodes in array order behind the places of the top, unless it is one of the top nodes
+// (listed breadth-first in `top`), whose place is its number there.
+__global__ void __launch_bounds__(256) tree_places_kernel(int n_nodes, const int *__restrict__ head, const int *__restrict__ rank, int top_places, int *__restrict__ where) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_nodes) return;
     where[i] = head[i] ? top_places + rank[i] : -1;
 }
-__global__ void tree_wide_top_kernel(const int *__restrict__ top, int n_top, int *__restrict__ where) {
+__global__ void tree_top_places_kernel(const int *__restrict__ top, int n_top, int *__restrict__ where) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_top) where[top[k]] = k;
 }
@@ -835,23 +840,31 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
     return 0;
 }
 
-int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
+int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *top, int n_top, int n_interior, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
                          int n_triangles, const rt_instance *d_instances, float id_scale, bool keep_nodes, DeviceBvh &out, std::string &err) {
     out = DeviceBvh();
+    if (n_top < 0 || n_top > TOP_RECORDS || n_interior < n_top) {
+        err = "rt_scene_create: bad list of the tree's top nodes";
+        return 3;
+    }
     Scratch mem;
+    // the top nodes' records take the first n_top places; every interior node's number in array order, behind them, is its
+    // place otherwise (the places of the top nodes in that numbering stay empty)
+    const int n_records = n_interior > 0 ? n_top + n_interior : 0;
     rt_bvh_node *d_nodes_in = mem.get<rt_bvh_node>((size_t)n_nodes);
-    int *d_record_of = mem.get<int>((size_t)n_nodes);
+    int *d_record_of = mem.get<int>((size_t)n_nodes), *d_interior = mem.get<int>((size_t)n_nodes), *d_rank = mem.get<int>((size_t)n_nodes), *d_top = mem.get<int>((size_t)TOP_RECORDS);
     rt_bvh_prim *d_in = mem.get<rt_bvh_prim>((size_t)n);
     float4 *d_records = mem.get<float4>(4 * (size_t)n_records), *d_prims = mem.get<float4>(PRIM_STRIDE * (size_t)n);
     int4 *d_meta = mem.get<int4>(2 * (size_t)n);
-    if (!d_nodes_in || !d_record_of || !d_in || !d_records || !d_prims || !d_meta) {
+    size_t scan_bytes = 0;
+    BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_interior, d_rank, std::max(n_nodes, 1)));
+    void *scan_temp = mem.get<char>(scan_bytes);
+    if (!d_nodes_in || !d_record_of || !d_interior || !d_rank || !d_top || !d_in || !d_records || !d_prims || !d_meta || !scan_temp) {
         err = "rt_scene_create: out of device memory for the tree's records";
         return 10;
     }
-    if (n_nodes > 0) {
-        BVH_HIP_OK(hipMemcpy(d_nodes_in, nodes, (size_t)n_nodes * sizeof(rt_bvh_node), hipMemcpyHostToDevice));
-        BVH_HIP_OK(hipMemcpy(d_record_of, record_of, (size_t)n_nodes * sizeof(int), hipMemcpyHostToDevice));
-    }
+    if (n_nodes > 0) BVH_HIP_OK(hipMemcpy(d_nodes_in, nodes, (size_t)n_nodes * sizeof(rt_bvh_node), hipMemcpyHostToDevice));
+    if (n_top > 0) BVH_HIP_OK(hipMemcpy(d_top, top, (size_t)n_top * sizeof(int), hipMemcpyHostToDevice));
     if (n > 0) BVH_HIP_OK(hipMemcpy(d_in, prims, (size_t)n * sizeof(rt_bvh_prim), hipMemcpyHostToDevice));
     if (n > 0)
         hipLaunchKernelGGL(entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, (const float *)nullptr, (const unsigned *)nullptr, n, d_triangles, n_triangles,
@@ -859,7 +872,14 @@ int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *recor
     if (n_nodes > 0) {
         const unsigned blocks = (unsigned)((n_nodes + 255) / 256);
         hipLaunchKernelGGL(leaf_boxes_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes_in, n_nodes, d_prims);
-        if (n_records > 0) hipLaunchKernelGGL(node_records_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes_in, n_nodes, d_record_of, d_records);
+        if (n_records > 0) {
+            BVH_HIP_OK(hipMemsetAsync(d_records, 0, 4 * (size_t)n_records * sizeof(float4), 0));
+            hipLaunchKernelGGL(tree_interior_kernel, dim3(blocks), dim3(256), 0, 0, (const rt_bvh_node *)d_nodes_in, n_nodes, d_interior);
+            BVH_HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, d_interior, d_rank, n_nodes));
+            hipLaunchKernelGGL(tree_places_kernel, dim3(blocks), dim3(256), 0, 0, n_nodes, (const int *)d_interior, (const int *)d_rank, n_top, d_record_of);
+            hipLaunchKernelGGL(tree_top_places_kernel, dim3(1), dim3(128), 0, 0, (const int *)d_top, n_top, d_record_of);
+            hipLaunchKernelGGL(node_records_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes_in, n_nodes, d_record_of, d_records);
+        }
     }
     BVH_HIP_OK(hipGetLastError());
     BVH_HIP_OK(hipDeviceSynchronize());
@@ -907,8 +927,8 @@ int wide_records_of_host_tree(const rt_bvh_node *d_nodes, int n_nodes, const int
         return 10;
     }
     BVH_HIP_OK(hipMemsetAsync(d_wnodes, 0, 4 * n_records * sizeof(float4), 0));
-    hipLaunchKernelGGL(tree_wide_places_kernel, dim3(blocks), dim3(256), 0, 0, n_nodes, (const int *)head, (const int *)rank, TOP_RECORDS, where);
-    hipLaunchKernelGGL(tree_wide_top_kernel, dim3(1), dim3(128), 0, 0, (const int *)d_top, n_top, where);
+    hipLaunchKernelGGL(tree_places_kernel, dim3(blocks), dim3(256), 0, 0, n_nodes, (const int *)head, (const int *)rank, TOP_RECORDS, where);
+    hipLaunchKernelGGL(tree_top_places_kernel, dim3(1), dim3(128), 0, 0, (const int *)d_top, n_top, where);
     hipLaunchKernelGGL(tree_wide_records_kernel, dim3(blocks), dim3(256), 0, 0, d_nodes, n_nodes, (const int *)where, d_wnodes, words + 1);
     BVH_HIP_OK(hipGetLastError());
     int unsound = 1;

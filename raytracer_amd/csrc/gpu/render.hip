@@ -2010,41 +2010,26 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     DevScene &D = s->dev;
     auto keep = [&](void *p) { s->allocations.push_back(p); };
 
-    // BVH -> interior-node records holding both child boxes (see DevScene); leaves become references.  The host decides
-    // where every record goes; records and leaf entries are written on the device (records_of_host_tree).
-    // Order of the records: the top of the tree breadth-first (the first TOP_NODES interior nodes a breadth-first
-    // walk meets; the trace kernel keeps them in LDS), then every subtree below depth-first (a node's left child
-    // next to it, a small subtree in a few cache lines).
-    std::vector<int> interior_index(d->n_bvh_nodes, -1);
+    // BVH -> interior-node records holding both child boxes (see DevScene); leaves become references.  Records and leaf
+    // entries are written on the device (records_of_host_tree).  Order of the records: the top of the tree breadth-first (the
+    // first TOP_NODES interior nodes a breadth-first walk meets, listed here; the trace kernel keeps them in LDS), then the
+    // other interior nodes in the order of the reference's array, which is depth-first (src/bvh.cpp:316-344: a node's left
+    // child next to it, a small subtree in a few cache lines).
+    std::vector<int> top_interior;
     int n_interior = 0, root_ref = 0;
     {
-        std::vector<int> walk, below;
+        for (int i = 0; i < d->n_bvh_nodes; ++i) n_interior += d->bvh_nodes[i].n_prims == 0 ? 1 : 0;
+        std::vector<int> walk;
         if (d->n_bvh_nodes > 0 && d->bvh_nodes[0].n_prims == 0) walk.push_back(0);
-        for (size_t at = 0; at < walk.size(); ++at) {
+        for (size_t at = 0; at < walk.size() && (int)top_interior.size() < TOP_NODES; ++at) {
             const int i = walk[at];
-            if (n_interior >= TOP_NODES) {
-                below.push_back(i);
-                continue;
-            }
-            interior_index[i] = n_interior++;
+            top_interior.push_back(i);
             const int kids[2] = {i + 1, d->bvh_nodes[i].offset};
             for (int kid : kids)
                 if (d->bvh_nodes[kid].n_prims == 0) walk.push_back(kid);
         }
-        s->dev.n_top = n_interior;
-        std::vector<int> stack;
-        for (int root : below) {
-            stack.push_back(root);
-            while (!stack.empty()) {
-                const int i = stack.back();
-                stack.pop_back();
-                interior_index[i] = n_interior++;
-                const int left = i + 1, right = d->bvh_nodes[i].offset;
-                if (d->bvh_nodes[right].n_prims == 0) stack.push_back(right);
-                if (d->bvh_nodes[left].n_prims == 0) stack.push_back(left);
-            }
-        }
-        if (d->n_bvh_nodes > 0) root_ref = d->bvh_nodes[0].n_prims == 0 ? interior_index[0] : (int)(0x80000000u | (unsigned)d->bvh_nodes[0].offset);
+        s->dev.n_top = (int)top_interior.size();
+        if (d->n_bvh_nodes > 0) root_ref = d->bvh_nodes[0].n_prims == 0 ? 0 : (int)(0x80000000u | (unsigned)d->bvh_nodes[0].offset);
     }
     clock.mark("places of the node records");
     // the inverse of the identity as this scene's inverse routine makes it (see plain_placement): the first such placement's
@@ -2100,7 +2085,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     } else {
         const char *wide_env = getenv("RT_WIDE_NODES");
         const bool keep_nodes = !(wide_env && atoi(wide_env) == 0) && d->n_bvh_nodes >= 3 && d->bvh_nodes[0].n_prims == 0;
-        if (int rc = records_of_host_tree(d->bvh_nodes, d->n_bvh_nodes, interior_index.data(), n_interior, d->bvh_prims, d->n_bvh_prims, D.triangles, d->n_triangles,
+        if (int rc = records_of_host_tree(d->bvh_nodes, d->n_bvh_nodes, top_interior.data(), (int)top_interior.size(), n_interior, d->bvh_prims, d->n_bvh_prims, D.triangles, d->n_triangles,
                                           D.instances, id_scale, keep_nodes, built, g_error)) {
             rt_scene_destroy(s);
             return rc;

@@ -32,10 +32,12 @@ int build_bvh_on_device(const rt_bvh_prim *prims, const float *bounds, int n, co
                         const rt_instance *d_instances, float id_scale, int max_depth, int wide_stack_entries, DeviceBvh &out, std::string &err);
 
 // The records of a tree that came with the scene, made on the device from the reference's node array (src/bvh.h:9-28; nodes,
-// record_of and prims in host memory): `record_of[i]` is where interior node i's two-box record goes (n_records places in
-// all), leaf entries keep the order of `prims`.  Fills out.nodes, out.prims, out.prim_meta (owned by the caller, as above).
+// top and prims in host memory): the two-box records of the `n_top` interior nodes listed in `top` (the tree's top, breadth
+// first, root first) take the first places, every other interior node's record the place n_top + its number among the
+// n_interior interior nodes in array order; leaf entries keep the order of `prims`.  Fills out.nodes, out.prims,
+// out.prim_meta (owned by the caller, as above).
 // `keep_nodes`: the uploaded node array stays on the device (out.tree_nodes, owned by the caller) for wide_records_of_host_tree.
-int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *record_of, int n_records, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
+int records_of_host_tree(const rt_bvh_node *nodes, int n_nodes, const int *top, int n_top, int n_interior, const rt_bvh_prim *prims, int n, const rt_triangle *d_triangles,
                          int n_triangles, const rt_instance *d_instances, float id_scale, bool keep_nodes, DeviceBvh &out, std::string &err);
 
 // The four-box records (DevScene::wnodes) of a tree that came with the scene, from its node array on the device: the records
